@@ -1,0 +1,167 @@
+"""ctypes front-end for oracle/bwdtrans_ref.c plus an independent numpy restatement.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Every function cites the reference lines
+its C counterpart follows; the numpy `einsum` forms are a second, independent statement of the
+same maths used to cross-check the C loop nests.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_LIBS = {}
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    want = [os.path.join(_BUILD, n) for n in ("liboracle.so", "liboracle_fast.so")]
+    src = os.path.join(_HERE, "bwdtrans_ref.c")
+    if force or not all(os.path.exists(w) and os.path.getmtime(w) >= os.path.getmtime(src)
+                        for w in want):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return want
+
+
+def _lib(fast=False):
+    key = "fast" if fast else "parity"
+    if key not in _LIBS:
+        path = os.path.join(_BUILD, "liboracle_fast.so" if fast else "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        lib = ctypes.CDLL(path)
+        sz, u32, u64, dbl = ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint64, ctypes.c_double
+        lib.oracle_max_threads.restype = ctypes.c_int
+        lib.oracle_fill_sincos.argtypes = [_c_dp, sz, sz]
+        lib.oracle_fill_basis.argtypes = [_c_dp, sz, sz]
+        lib.oracle_fill_random.argtypes = [_c_dp, sz, u64, u64]
+        lib.oracle_random_value.argtypes = [u64, u64]
+        lib.oracle_random_value.restype = dbl
+        lib.oracle_fill_l2norm.argtypes = [_c_dp, sz]
+        lib.oracle_sumsq.argtypes = [_c_dp, sz]
+        lib.oracle_sumsq.restype = dbl
+        for name in ("oracle_bwdtrans_hex_fused", "oracle_bwdtrans_hex_sweeps"):
+            f = getattr(lib, name)
+            f.argtypes = [u32, u32, u32, sz, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
+            f.restype = ctypes.c_int
+        for name in ("oracle_bwdtrans_quad_fused", "oracle_bwdtrans_quad_sweeps"):
+            f = getattr(lib, name)
+            f.argtypes = [u32, u32, sz, _c_dp, _c_dp, _c_dp, _c_dp]
+            f.restype = ctypes.c_int
+        _LIBS[key] = lib
+    return _LIBS[key]
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_c_dp)
+
+
+def max_threads():
+    return int(_lib().oracle_max_threads())
+
+
+# ---------------------------------------------------------------- initialisers -----------------
+
+def fill_sincos(nelmt, nm_tot):
+    """in[e][f] = sin(f+1), every element identical (benchmark05/benchmark05.cc:1206-1207)."""
+    a = np.empty(nelmt * nm_tot, dtype=np.float64)
+    _lib().oracle_fill_sincos(_p(a), nelmt, nm_tot)
+    return a
+
+
+def fill_basis(nm, nq):
+    """basis[p*nq+i] = cos(p*nq+i) (benchmark05/benchmark05.cc:1216-1222)."""
+    a = np.empty(nm * nq, dtype=np.float64)
+    _lib().oracle_fill_basis(_p(a), nm, nq)
+    return a
+
+
+def fill_random(n, seed, first_idx=0):
+    """Counter-based U[-1,1): value = f(seed, first_idx + i).  Not in the reference."""
+    a = np.empty(n, dtype=np.float64)
+    _lib().oracle_fill_random(_p(a), n, seed, first_idx)
+    return a
+
+
+def random_value_py(seed, idx):
+    """Pure-Python statement of the generator (pins the C and the HIP implementations)."""
+    m = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        return z ^ (z >> 31)
+
+    h = mix((seed ^ mix(idx)) & m)
+    return float(h >> 11) * (2.0 / 9007199254740992.0) - 1.0
+
+
+def fill_l2norm(n):
+    """x[i] = i%13 + (0.2 + 1e-5*(i%100191)) (benchmark01/benchmark01.cc:178)."""
+    a = np.empty(n, dtype=np.float64)
+    _lib().oracle_fill_l2norm(_p(a), n)
+    return a
+
+
+def sumsq(x, fast=False):
+    """sum x^2, pairwise (benchmark05/benchmark05.cc:1273-1276 semantics; sqrt at print :1397)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    return float(_lib(fast).oracle_sumsq(_p(x), x.size))
+
+
+# ---------------------------------------------------------------- BwdTrans ---------------------
+
+def bwdtrans_hex(nq, nelmt, b0, b1, b2, inp, form="sweeps", fast=False):
+    """3D hex BwdTrans.  form='fused' -> benchmark05.cc:57-101, 'sweeps' -> :361-423."""
+    nq0, nq1, nq2 = nq
+    out = np.empty(nelmt * nq0 * nq1 * nq2, dtype=np.float64)
+    f = getattr(_lib(fast), "oracle_bwdtrans_hex_" + form)
+    rc = f(nq0, nq1, nq2, nelmt, _p(b0), _p(b1), _p(b2), _p(inp), _p(out))
+    if rc != 0:
+        raise ValueError(f"oracle_bwdtrans_hex_{form} rc={rc}")
+    return out
+
+
+def bwdtrans_quad(nq, nelmt, b0, b1, inp, form="sweeps", fast=False):
+    """2D quad BwdTrans.  form='fused' -> benchmark04.cc:49-72, 'sweeps' -> :393-420."""
+    nq0, nq1 = nq
+    out = np.empty(nelmt * nq0 * nq1, dtype=np.float64)
+    f = getattr(_lib(fast), "oracle_bwdtrans_quad_" + form)
+    rc = f(nq0, nq1, nelmt, _p(b0), _p(b1), _p(inp), _p(out))
+    if rc != 0:
+        raise ValueError(f"oracle_bwdtrans_quad_{form} rc={rc}")
+    return out
+
+
+def bwdtrans_hex_numpy(nq, nelmt, b0, b1, b2, inp):
+    """Independent statement: out[e,k,j,i] = sum_rqp in[e,r,q,p] B0[p,i] B1[q,j] B2[r,k]."""
+    nq0, nq1, nq2 = nq
+    nm0, nm1, nm2 = nq0 - 1, nq1 - 1, nq2 - 1
+    u = inp.reshape(nelmt, nm2, nm1, nm0)
+    out = np.einsum("erqp,pi,qj,rk->ekji", u, b0.reshape(nm0, nq0), b1.reshape(nm1, nq1),
+                    b2.reshape(nm2, nq2), optimize=True)
+    return np.ascontiguousarray(out).ravel()
+
+
+def bwdtrans_quad_numpy(nq, nelmt, b0, b1, inp):
+    """Independent statement: out[e,j,i] = sum_qp in[e,q,p] B0[p,i] B1[q,j]."""
+    nq0, nq1 = nq
+    nm0, nm1 = nq0 - 1, nq1 - 1
+    u = inp.reshape(nelmt, nm1, nm0)
+    out = np.einsum("eqp,pi,qj->eji", u, b0.reshape(nm0, nq0), b1.reshape(nm1, nq1),
+                    optimize=True)
+    return np.ascontiguousarray(out).ravel()
+
+
+def rel_err(a, ref):
+    """Norm-wise relative error max|a-ref| / max|ref| (outputs have cancellation)."""
+    ref = np.asarray(ref)
+    d = float(np.max(np.abs(np.asarray(a) - ref))) if ref.size else 0.0
+    m = float(np.max(np.abs(ref))) if ref.size else 0.0
+    return d / m if m > 0 else d
