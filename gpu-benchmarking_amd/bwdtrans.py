@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's kernel call sites, over torch device tensors.
+
+torch is plumbing only (device memory, streams); all arithmetic happens in libsumfact.so.
+Argument meaning follows the reference kernels (benchmark05/benchmark05.cc:291-297,
+benchmark04/benchmark04.cc:353-358): extents nq (nm = nq-1), basis row-major nm x nq,
+in[e][r][q][p], out[e][k][j][i].
+"""
+import ctypes
+
+import torch
+
+from . import capi
+
+VARIANTS = {"auto": 0, "wave": 1, "thread": 2, "block-lds": 3, "block-glb": 4, "generic": 5,
+            "mfma": 6}
+
+
+def _stream(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _dev_f64(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64
+            and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float64 CUDA/HIP tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _variant(v):
+    return VARIANTS[v] if isinstance(v, str) else int(v)
+
+
+def hex_wsp_doubles(nq, nelmt):
+    """Workspace the block-glb / thread variants need (benchmark05/benchmark05.cc:1243-1244)."""
+    nq0, nq1, nq2 = nq
+    return nelmt * (nq0 * (nq1 - 1) * (nq2 - 1) + nq0 * nq1 * (nq2 - 1))
+
+
+def quad_wsp_doubles(nq, nelmt):
+    """Workspace of the 2D block-glb / thread variants (benchmark04/benchmark04.cc:894)."""
+    nq0, nq1 = nq
+    return nelmt * nq0 * (nq1 - 1)
+
+
+def bwdtrans_hex(nq, basis0, basis1, basis2, inp, out=None, variant="auto", wsp=None, stream=None):
+    """out[e][k][j][i] = sum_rqp in[e][r][q][p] B0[p][i] B1[q][j] B2[r][k] on inp's device."""
+    nq0, nq1, nq2 = (int(x) for x in nq)
+    nmt = (nq0 - 1) * (nq1 - 1) * (nq2 - 1)
+    if nmt <= 0:
+        raise capi.SumfactError(capi.SF_EINVAL, "bwdtrans_hex")
+    nelmt = inp.numel() // nmt
+    if nelmt * nmt != inp.numel():
+        raise ValueError("in.numel() is not a multiple of nm0*nm1*nm2")
+    if out is None:
+        out = torch.empty(nelmt * nq0 * nq1 * nq2, dtype=torch.float64, device=inp.device)
+    elif out.numel() != nelmt * nq0 * nq1 * nq2:
+        raise ValueError("out has the wrong size")
+    v = _variant(variant)
+    if wsp is None and v in (2, 4) and nelmt:
+        wsp = torch.empty(hex_wsp_doubles((nq0, nq1, nq2), nelmt), dtype=torch.float64,
+                          device=inp.device)
+    with torch.cuda.device(inp.device):
+        rc = capi.lib().sf_bwdtrans_hex_f64_variant(
+            v, nq0, nq1, nq2, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
+            _dev_f64(basis2, "basis2"), _dev_f64(inp, "in"),
+            _dev_f64(wsp, "wsp") if wsp is not None else None, _dev_f64(out, "out"),
+            _stream(stream))
+    capi.check(rc, "sf_bwdtrans_hex_f64")
+    return out
+
+
+def bwdtrans_quad(nq, basis0, basis1, inp, out=None, variant="auto", wsp=None, stream=None):
+    """out[e][j][i] = sum_qp in[e][q][p] B0[p][i] B1[q][j] on inp's device."""
+    nq0, nq1 = (int(x) for x in nq)
+    nmt = (nq0 - 1) * (nq1 - 1)
+    if nmt <= 0:
+        raise capi.SumfactError(capi.SF_EINVAL, "bwdtrans_quad")
+    nelmt = inp.numel() // nmt
+    if nelmt * nmt != inp.numel():
+        raise ValueError("in.numel() is not a multiple of nm0*nm1")
+    if out is None:
+        out = torch.empty(nelmt * nq0 * nq1, dtype=torch.float64, device=inp.device)
+    elif out.numel() != nelmt * nq0 * nq1:
+        raise ValueError("out has the wrong size")
+    v = _variant(variant)
+    if wsp is None and v in (2, 4) and nelmt:
+        wsp = torch.empty(quad_wsp_doubles((nq0, nq1), nelmt), dtype=torch.float64,
+                          device=inp.device)
+    with torch.cuda.device(inp.device):
+        rc = capi.lib().sf_bwdtrans_quad_f64_variant(
+            v, nq0, nq1, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
+            _dev_f64(inp, "in"), _dev_f64(wsp, "wsp") if wsp is not None else None,
+            _dev_f64(out, "out"), _stream(stream))
+    capi.check(rc, "sf_bwdtrans_quad_f64")
+    return out
+
+
+def sumsq(x, stream=None):
+    """sum x^2 (blocking; deterministic) -- the reference's thrust::transform_reduce."""
+    res = ctypes.c_double(0.0)
+    with torch.cuda.device(x.device):
+        rc = capi.lib().sf_sumsq_f64(_dev_f64(x, "x"), x.numel(), ctypes.byref(res),
+                                     _stream(stream))
+    capi.check(rc, "sf_sumsq_f64")
+    return res.value
+
+
+def _filled(n, device, call, what):
+    x = torch.empty(n, dtype=torch.float64, device=device)
+    with torch.cuda.device(x.device):
+        capi.check(call(_dev_f64(x, "x")), what)
+    return x
+
+
+def fill_sincos(nelmt, nm_tot, device="cuda", stream=None):
+    """in[e][f] = sin(f+1) (benchmark05/benchmark05.cc:1206-1207), generated on the device."""
+    st = _stream(stream)
+    return _filled(nelmt * nm_tot, device,
+                   lambda p: capi.lib().sf_fill_sincos_f64(p, nelmt, nm_tot, st),
+                   "sf_fill_sincos_f64")
+
+
+def fill_basis(nm, nq, device="cuda", stream=None):
+    """basis[x] = cos(x) (benchmark05/benchmark05.cc:1220)."""
+    st = _stream(stream)
+    return _filled(nm * nq, device, lambda p: capi.lib().sf_fill_basis_f64(p, nm, nq, st),
+                   "sf_fill_basis_f64")
+
+
+def fill_random(n, seed, first_idx=0, device="cuda", stream=None):
+    """Seeded per-value-distinct U[-1,1) data; bit-identical to oracle.fill_random."""
+    st = _stream(stream)
+    return _filled(n, device,
+                   lambda p: capi.lib().sf_fill_random_f64(p, n, seed, first_idx, st),
+                   "sf_fill_random_f64")
+
+
+def fill_l2norm(n, device="cuda", stream=None):
+    """x[i] = i%13 + (0.2 + 1e-5*(i%100191)) (benchmark01/benchmark01.cc:178)."""
+    st = _stream(stream)
+    return _filled(n, device, lambda p: capi.lib().sf_fill_l2norm_f64(p, n, st),
+                   "sf_fill_l2norm_f64")
+
+
+def stream_copy(src, dst, stream=None):
+    with torch.cuda.device(src.device):
+        capi.check(capi.lib().sf_stream_copy_f64(_dev_f64(src, "src"), _dev_f64(dst, "dst"),
+                                                 src.numel(), _stream(stream)),
+                   "sf_stream_copy_f64")
+    return dst
+
+
+def device_info():
+    cu, wave = ctypes.c_int(0), ctypes.c_int(0)
+    name = ctypes.create_string_buffer(256)
+    capi.check(capi.lib().sf_device_info(ctypes.byref(cu), ctypes.byref(wave), name, 256),
+               "sf_device_info")
+    return {"num_cu": cu.value, "wave_size": wave.value, "name": name.value.decode()}

@@ -1,0 +1,332 @@
+// aux_kernels.hip -- initialisers, sum-of-squares reduction and the HBM stream calibrator.
+//
+//   fill_sincos / fill_basis : device-side version of the host init loops
+//                              benchmark05/benchmark05.cc:1195-1236, benchmark04/benchmark04.cc:859-889
+//   fill_l2norm              : benchmark01/benchmark01.cc:171-181 (set_data)
+//   fill_random              : per-value-distinct seeded data (not in the reference; same generator as
+//                              oracle_fill_random so host and device arrays agree bit for bit)
+//   sumsq                    : thrust::transform_reduce(x*x, plus) of benchmark05.cc:1273-1276 and the
+//                              l2norm kernels of benchmark01/benchmark01.cc:15-77, 112-169
+//   stream_copy              : bandwidth calibrator (cf. benchmark02/benchmark02.cc:16-58)
+#include "sf_common.h"
+
+#include <mutex>
+
+namespace sf
+{
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_sincos_kernel(double *__restrict__ in, uint64_t total,
+                                                          uint32_t nm_tot)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride)
+    {
+        const uint32_t f = (uint32_t)(x % nm_tot);
+        in[x]            = sin((double)(f + 1u));
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_basis_kernel(double *__restrict__ b, uint32_t n)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n)
+        b[x] = cos((double)x);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_random_kernel(double *__restrict__ x, uint64_t n,
+                                                          uint64_t seed, uint64_t first)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const uint64_t h = mix64(seed ^ mix64(first + i));
+        x[i]             = (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_l2norm_kernel(double *__restrict__ x, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const uint32_t u = (uint32_t)i;
+        x[i]             = u % 13u + (0.2 + 0.00001 * (u % 100191u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum of squares: pass 1 = per-block partials (fixed grid for a given n -> deterministic),
+// pass 2 = one block folds the partials.  16-B lanes, 4 independent accumulators per lane,
+// wave-64 shuffle tree, one LDS slot per wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRedThreads  = 256;
+constexpr int kRedMaxBlock = 2048;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    if (lane == 0)
+        red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+    {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i)
+            s += red[i];
+    }
+    return s; // valid in thread 0
+}
+
+__global__ __launch_bounds__(kRedThreads) void sumsq_partial_kernel(const double *__restrict__ x,
+                                                                    uint64_t n,
+                                                                    double *__restrict__ part)
+{
+    __shared__ double red[kRedThreads / kWave];
+    const uint64_t nv     = n / 2; // double2 units (x is 16-B aligned, checked on the host)
+    const double2_t *x2   = reinterpret_cast<const double2_t *>(x);
+    const uint64_t stride = (uint64_t)gridDim.x * kRedThreads;
+    uint64_t v            = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (; v + stride < nv; v += 2 * stride)
+    {
+        const double2_t p = x2[v], q = x2[v + stride];
+        a0 = __builtin_fma(p.x, p.x, a0);
+        a1 = __builtin_fma(p.y, p.y, a1);
+        a2 = __builtin_fma(q.x, q.x, a2);
+        a3 = __builtin_fma(q.y, q.y, a3);
+    }
+    if (v < nv)
+    {
+        const double2_t p = x2[v];
+        a0                = __builtin_fma(p.x, p.x, a0);
+        a1                = __builtin_fma(p.y, p.y, a1);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        a2 = __builtin_fma(x[n - 1], x[n - 1], a2);
+    const double s = block_sum((a0 + a1) + (a2 + a3), red);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kRedThreads) void sumsq_final_kernel(const double *__restrict__ part,
+                                                                  int npart,
+                                                                  double *__restrict__ result)
+{
+    __shared__ double red[kRedThreads / kWave];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < npart; i += kRedThreads)
+        a += part[i];
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0)
+        result[0] = s;
+}
+
+// scalar (8-byte lanes) variant for unaligned x
+__global__ __launch_bounds__(kRedThreads) void sumsq_partial_scalar_kernel(
+    const double *__restrict__ x, uint64_t n, double *__restrict__ part)
+{
+    __shared__ double red[kRedThreads / kWave];
+    const uint64_t stride = (uint64_t)gridDim.x * kRedThreads;
+    double a              = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += stride)
+        a = __builtin_fma(x[i], x[i], a);
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_copy_kernel(const double2_t *__restrict__ src,
+                                                          double2_t *__restrict__ dst, uint64_t nv)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+const DeviceInfo &device_info()
+{
+    static DeviceInfo info[64];
+    static bool have[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64)
+        dev = 0;
+    if (!have[dev])
+    {
+        int cu = 256;
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        info[dev].num_cu = cu > 0 ? cu : 256;
+        info[dev].device = dev;
+        have[dev]        = true;
+    }
+    return info[dev];
+}
+
+struct Workspace
+{
+    double *part   = nullptr; // kRedMaxBlock partials + 1 result
+    double *result = nullptr;
+};
+
+static Workspace g_ws[64];
+static std::mutex g_ws_mu;
+
+static int workspace(Workspace **ws)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64)
+        return SF_EINVAL;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    Workspace &w = g_ws[dev];
+    if (!w.part)
+    {
+        hipError_t e = hipMalloc((void **)&w.part, sizeof(double) * (kRedMaxBlock + 8));
+        if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return SF_ENOMEM;
+        }
+        w.result = w.part + kRedMaxBlock;
+    }
+    *ws = &w;
+    return SF_OK;
+}
+
+int release_workspaces()
+{
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && g_ws[dev].part)
+    {
+        (void)hipFree(g_ws[dev].part);
+        g_ws[dev] = Workspace();
+    }
+    return SF_OK;
+}
+
+static inline int launch_rc()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+static inline unsigned fill_grid(uint64_t n)
+{
+    const uint64_t want = (n + 255) / 256;
+    const uint64_t cap  = (uint64_t)device_info().num_cu * 16;
+    return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s)
+{
+    Workspace *ws = nullptr;
+    int rc        = workspace(&ws);
+    if (rc != SF_OK)
+        return rc;
+    // fixed shape for a given n: deterministic result
+    uint64_t blocks = (n / 2 + (uint64_t)kRedThreads * 8 - 1) / ((uint64_t)kRedThreads * 8);
+    if (blocks < 1)
+        blocks = 1;
+    if (blocks > kRedMaxBlock)
+        blocks = kRedMaxBlock;
+    if (((uintptr_t)x & 15u) == 0)
+        sumsq_partial_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
+    else
+        sumsq_partial_scalar_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
+    sumsq_final_kernel<<<1, kRedThreads, 0, s>>>(ws->part, (int)blocks,
+                                                 result_dev ? result_dev : ws->result);
+    return launch_rc();
+}
+
+int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s)
+{
+    Workspace *ws = nullptr;
+    int rc        = workspace(&ws);
+    if (rc != SF_OK)
+        return rc;
+    rc = sumsq_async(x, n, ws->result, s);
+    if (rc != SF_OK)
+        return rc;
+    hipError_t e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+int fill_sincos(double *in, size_t nelmt, size_t nm_tot, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)nelmt * nm_tot;
+    if (total == 0)
+        return SF_OK;
+    fill_sincos_kernel<<<fill_grid(total), 256, 0, s>>>(in, total, (uint32_t)nm_tot);
+    return launch_rc();
+}
+
+int fill_basis(double *b, size_t nm, size_t nq, hipStream_t s)
+{
+    const uint32_t n = (uint32_t)(nm * nq);
+    if (n == 0)
+        return SF_OK;
+    fill_basis_kernel<<<(n + 255) / 256, 256, 0, s>>>(b, n);
+    return launch_rc();
+}
+
+int fill_random(double *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    fill_random_kernel<<<fill_grid(n), 256, 0, s>>>(x, n, seed, first);
+    return launch_rc();
+}
+
+int fill_l2norm(double *x, size_t n, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    fill_l2norm_kernel<<<fill_grid(n), 256, 0, s>>>(x, n);
+    return launch_rc();
+}
+
+int stream_copy(const double *src, double *dst, size_t n, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) != 0 || (n & 1))
+        return SF_EALIGN;
+    const uint64_t nv = n / 2;
+    uint64_t blocks   = (nv + 255) / 256;
+    const uint64_t cap = (uint64_t)device_info().num_cu * 8;
+    if (blocks > cap)
+        blocks = cap;
+    stream_copy_kernel<<<(unsigned)blocks, 256, 0, s>>>(reinterpret_cast<const double2_t *>(src),
+                                                        reinterpret_cast<double2_t *>(dst), nv);
+    return launch_rc();
+}
+
+} // namespace sf

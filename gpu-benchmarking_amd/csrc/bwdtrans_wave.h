@@ -1,0 +1,465 @@
+// bwdtrans_wave.h -- flagship BwdTrans kernels for gfx950: one WAVEFRONT streams chunks of elements.
+//
+// Replaces the reference's block-per-element kernels BwdTransHexKernel_QP (shared)
+// (benchmark05/benchmark05.cc:291-429) and BwdTransQuadKernel_QP_1D (shared)
+// (benchmark04/benchmark04.cc:353-426).  Same maths and the same sweep order (p, then q, then r,
+// ascending summation inside each dot product); everything else is designed for CDNA4:
+//
+//  * Work unit = a CHUNK of EC consecutive elements owned by ONE 64-lane wavefront.  No workgroup
+//    barrier in the element loop (the reference pays 4 __syncthreads per element); lanes of the wave
+//    hand data to each other through a private LDS slab, ordered by wave_lds_fence().
+//  * Persistent grid: wave w handles chunks w, w+W, w+2W ...; the bases are staged in LDS once per
+//    workgroup (the reference reloads them per block = per element).
+//  * HBM -> registers with flat, coalesced 16-B-per-lane loads of the whole chunk (EC*nm^d doubles
+//    are contiguous), issued one chunk AHEAD and parked in VGPRs while the current chunk is computed
+//    (software pipelining without LDS double buffers) -> LDS slab.
+//  * A sweep is "lane owns a pencil": lane t reads its NIN-long pencil from LDS into registers,
+//    multiplies by the NIN x NOUT basis (wave-uniform operand) and scatters the NOUT results so that
+//    the next sweep's pencils are contiguous again.  Pencil stride in LDS is padded to an odd number of
+//    doubles -> conflict-free ds_read_b64.  Pencils of all EC elements are flattened over the lanes,
+//    so low orders fill the wave (nq=4: 4 elements per wave pass).
+//  * Last sweep: lane <-> (j,i), registers <-> k, so every store instruction writes nq^2 consecutive
+//    doubles of out[e][k][:][:] straight from registers (non-temporal).
+//
+// Algorithmic HBM traffic per element: 8*(nm^d + nq^d) bytes (in read once, out written once).
+#pragma once
+
+#include "sf_common.h"
+
+namespace sf
+{
+
+// How the wave-uniform basis operand is delivered to the FMAs.
+enum BasisMode
+{
+    BASIS_LDS = 0, // broadcast ds_read from the workgroup's LDS copy
+    BASIS_SMEM = 1 // scalar loads (s_load) from global memory -> SGPR operand
+};
+
+template <int NQ, int EC, int DIM> struct WaveGeom
+{
+    static constexpr int NM  = NQ - 1;
+    static constexpr int NMP = NM | 1; // padded pencil stride (odd number of doubles)
+    static constexpr int NMT = (DIM == 3) ? NM * NM * NM : NM * NM; // modes per element
+    static constexpr int NQT = (DIM == 3) ? NQ * NQ * NQ : NQ * NQ; // points per element
+    // input pencils keep the global layout when NM is odd (already conflict-free)
+    static constexpr int IN_STRIDE = (NM % 2 == 0) ? NM + 1 : NM;
+    static constexpr int IN_DBL    = EC * NMT;     // doubles per chunk in HBM
+    static constexpr bool VEC2     = (IN_DBL % 2) == 0;
+    // pencils per chunk in each sweep
+    static constexpr int P0 = (DIM == 3) ? EC * NM * NM : EC * NM; // (e,r,q) | (e,q)
+    static constexpr int P1 = (DIM == 3) ? EC * NQ * NM : EC * NQ; // (e,i,r) | (e,i)
+    static constexpr int P2 = EC * NQ * NQ;                       // (e,j,i)   (3D only)
+    static constexpr int PASS0 = cdiv(P0, kWave);
+    static constexpr int PASS1 = cdiv(P1, kWave);
+    static constexpr int PASS2 = cdiv(P2, kWave);
+    // LDS slab per wave (doubles): max over the three images that live in it, one after another
+    static constexpr int SLAB_IN = P0 * IN_STRIDE;
+    static constexpr int SLAB_W1 = P1 * NMP;
+    static constexpr int SLAB_W2 = (DIM == 3) ? P2 * NMP : 0;
+    static constexpr int SLAB0   = CMax<CMax<SLAB_IN, SLAB_W1>::value, SLAB_W2>::value;
+    static constexpr int SLAB    = (SLAB0 + 1) & ~1; // keep slabs 16-B aligned
+    static constexpr int NBAS    = (NM * NQ + 1) & ~1;
+    static constexpr int NLD     = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
+};
+
+template <int NQ, int EC, int DIM, int WPB> constexpr size_t wave_lds_bytes()
+{
+    using G = WaveGeom<NQ, EC, DIM>;
+    return sizeof(double) * (size_t)(DIM * G::NBAS + WPB * G::SLAB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// chunk load: global -> staging registers (issued one chunk ahead of its use)
+// ------------------------------------------------------------------------------------------------
+template <class G, bool FULL>
+__device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double *__restrict__ src,
+                                           int lane, int nvalid /*doubles, only if !FULL*/)
+{
+    if constexpr (G::VEC2)
+    {
+        const double2_t *src2 = reinterpret_cast<const double2_t *>(src);
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            if constexpr (FULL)
+            {
+                if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+                    st[k] = __builtin_nontemporal_load(src2 + v);
+            }
+            else
+            {
+                double2_t x = {0.0, 0.0};
+                if (2 * v + 1 < nvalid)
+                    x = __builtin_nontemporal_load(src2 + v);
+                else if (2 * v < nvalid)
+                    x.x = __builtin_nontemporal_load(src + 2 * v);
+                st[k] = x;
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            double x    = 0.0;
+            if (v < (FULL ? G::IN_DBL : nvalid))
+                x = __builtin_nontemporal_load(src + v);
+            st[k].x = x;
+        }
+    }
+}
+
+// staging registers -> LDS slab, pencil stride IN_STRIDE
+template <class G>
+__device__ __forceinline__ void chunk_stage(const double2_t (&st)[G::NLD], double *slab, int lane)
+{
+    if constexpr (G::VEC2)
+    {
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+            {
+                if constexpr (G::IN_STRIDE == G::NM)
+                {
+                    *reinterpret_cast<double2_t *>(slab + 2 * v) = st[k];
+                }
+                else
+                {
+                    const int f0 = 2 * v, f1 = 2 * v + 1;
+                    slab[f0 + f0 / G::NM] = st[k].x;
+                    slab[f1 + f1 / G::NM] = st[k].y;
+                }
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
+            {
+                if constexpr (G::IN_STRIDE == G::NM)
+                    slab[v] = st[k].x;
+                else
+                    slab[v + v / G::NM] = st[k].x;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one contraction: acc[pass][n] = sum_m u[pass][m] * B[m*NOUT + n], ascending m, start at 0
+// ------------------------------------------------------------------------------------------------
+template <int NIN, int NOUT, int NPASS, int BMODE>
+__device__ __forceinline__ void contract(const double (&u)[NPASS][NIN], double (&acc)[NPASS][NOUT],
+                                         const double *__restrict__ bas)
+{
+    // The basis is consumed one ROW (fixed m, all n) at a time, with the next row's operands
+    // requested before the current row's FMAs and a scheduling fence after them: left alone, hipcc
+    // hoists every basis load of the sweep (and of later sweeps) to the top and then spills.
+    int zero = 0;
+    if constexpr (BMODE == BASIS_SMEM)
+    {
+        // keep the scalar loads inside the chunk loop (an opaque OFFSET, not an opaque pointer: the
+        // pointer must stay a provably global, unclobbered kernel argument to get s_load)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    }
+    else
+    {
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    }
+    // ring of operand rows: scalar loads come from the K-cache / L2 (longer latency) -> 2 rows ahead
+    constexpr int PFD = (BMODE == BASIS_SMEM) ? 2 : 1, RING = PFD + 1;
+    double b[RING][NOUT];
+#pragma unroll
+    for (int r = 0; r < PFD && r < NIN; ++r)
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n)
+            b[r][n] = bas[zero + r * NOUT + n];
+#pragma unroll
+    for (int m = 0; m < NIN; ++m)
+    {
+        if (m + PFD < NIN)
+        {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n)
+                b[(m + PFD) % RING][n] = bas[zero + (m + PFD) * NOUT + n];
+        }
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n)
+        {
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s)
+                acc[s][n] = (m == 0) ? u[s][0] * b[0][n]
+                                     : __builtin_fma(u[s][m], b[m % RING][n], acc[s][n]);
+        }
+        // order fence: the next row's operand loads (addressed through `zero`) may not be issued
+        // before this row's FMAs, and this row's FMAs may not sink below them
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n)
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s)
+                asm volatile("" : "+s"(zero) : "v"(acc[s][n]));
+    }
+}
+
+// read the pencils of this lane: u[pass][m] = slab[t*STRIDE + m], t = pass*64 + lane < NP
+template <int NIN, int NPASS, int NP, int STRIDE>
+__device__ __forceinline__ void read_pencils(double (&u)[NPASS][NIN], const double *slab, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < NPASS; ++s)
+    {
+        int t = s * kWave + lane;
+        if ((s + 1) * kWave > NP) // partial pass: idle lanes re-read the last pencil (no branch)
+            t = t < NP ? t : NP - 1;
+#pragma unroll
+        for (int m = 0; m < NIN; ++m)
+            u[s][m] = slab[t * STRIDE + m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3D hex
+// ------------------------------------------------------------------------------------------------
+template <int NQ, int EC, int WPB, int BMODE, int MINW>
+__global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
+    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
+    const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
+{
+    using G          = WaveGeom<NQ, EC, 3>;
+    constexpr int NM = G::NM, NMP = G::NMP, NM2 = NM * NM, NQ2 = NQ * NQ;
+
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *sb0 = lds, *sb1 = lds + G::NBAS, *sb2 = lds + 2 * G::NBAS;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *slab   = lds + 3 * G::NBAS + wib * G::SLAB;
+
+    for (int x = threadIdx.x; x < NM * NQ; x += kWave * WPB)
+    {
+        sb0[x] = b0[x];
+        sb1[x] = b1[x];
+        sb2[x] = b2[x];
+    }
+    __syncthreads();
+    const double *bs0 = (BMODE == BASIS_SMEM) ? b0 : sb0;
+    const double *bs1 = (BMODE == BASIS_SMEM) ? b1 : sb1;
+    const double *bs2 = (BMODE == BASIS_SMEM) ? b2 : sb2;
+
+    const uint64_t nchunk = (nelmt + EC - 1) / EC;
+    const uint64_t nwave  = (uint64_t)gridDim.x * WPB;
+    uint64_t c            = (uint64_t)blockIdx.x * WPB + wib;
+    if (c >= nchunk)
+        return;
+
+    double2_t st[G::NLD];
+    {
+        const uint64_t left = nelmt - c * EC;
+        if (left >= EC)
+            chunk_load<G, true>(st, in + c * G::IN_DBL, lane, 0);
+        else
+            chunk_load<G, false>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
+    }
+
+    for (; c < nchunk; c += nwave)
+    {
+        const uint64_t left = nelmt - c * EC;
+        const int evalid    = left >= EC ? EC : (int)left;
+
+        chunk_stage<G>(st, slab, lane);
+        wave_lds_fence();
+
+        // prefetch the next chunk of this wave into the staging registers
+        {
+            const uint64_t cn = c + nwave;
+            if (cn < nchunk)
+            {
+                const uint64_t ln = nelmt - cn * EC;
+                if (ln >= EC)
+                    chunk_load<G, true>(st, in + cn * G::IN_DBL, lane, 0);
+                else
+                    chunk_load<G, false>(st, in + cn * G::IN_DBL, lane, (int)ln * G::NMT);
+            }
+        }
+
+        // ---- direction 0: w1[(e,i,r)][q] = sum_p in[(e,r,q)][p] * B0[p][i] ----------------------
+        {
+            double u[G::PASS0][NM], acc[G::PASS0][NQ];
+            read_pencils<NM, G::PASS0, G::P0, G::IN_STRIDE>(u, slab, lane);
+            contract<NM, NQ, G::PASS0, BMODE>(u, acc, bs0);
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < G::PASS0; ++s)
+            {
+                const int t = s * kWave + lane;
+                if ((s + 1) * kWave <= G::P0 || t < G::P0)
+                {
+                    const int e = t / NM2, rq = t - e * NM2, r = rq / NM, q = rq - r * NM;
+                    double *dst = slab + (e * NQ * NM + r) * NMP + q;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        dst[i * NM * NMP] = acc[s][i];
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- direction 1: w2[(e,j,i)][r] = sum_q w1[(e,i,r)][q] * B1[q][j] ----------------------
+        {
+            double u[G::PASS1][NM], acc[G::PASS1][NQ];
+            read_pencils<NM, G::PASS1, G::P1, NMP>(u, slab, lane);
+            contract<NM, NQ, G::PASS1, BMODE>(u, acc, bs1);
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < G::PASS1; ++s)
+            {
+                const int t = s * kWave + lane;
+                if ((s + 1) * kWave <= G::P1 || t < G::P1)
+                {
+                    const int e = t / (NQ * NM), ir = t - e * (NQ * NM), i = ir / NM,
+                              r = ir - i * NM;
+                    double *dst = slab + (e * NQ2 + i) * NMP + r;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j)
+                        dst[j * NQ * NMP] = acc[s][j];
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- direction 2: out[e][k][(j,i)] = sum_r w2[(e,j,i)][r] * B2[r][k] --------------------
+        {
+            double u[G::PASS2][NM], acc[G::PASS2][NQ];
+            read_pencils<NM, G::PASS2, G::P2, NMP>(u, slab, lane);
+            contract<NM, NQ, G::PASS2, BMODE>(u, acc, bs2);
+            double *oc = out + c * (uint64_t)(EC * G::NQT);
+#pragma unroll
+            for (int s = 0; s < G::PASS2; ++s)
+            {
+                const int t = s * kWave + lane;
+                const int e = t / NQ2, pl = t - e * NQ2;
+                if (((s + 1) * kWave <= G::P2 || t < G::P2) && e < evalid)
+                {
+                    double *dst = oc + e * G::NQT + pl;
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k)
+                        __builtin_nontemporal_store(acc[s][k], dst + k * NQ2);
+                }
+            }
+            wave_lds_fence(); // slab is rewritten by the next chunk's staging
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2D quad
+// ------------------------------------------------------------------------------------------------
+template <int NQ, int EC, int WPB, int BMODE, int MINW>
+__global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
+    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
+    double *__restrict__ out, uint64_t nelmt)
+{
+    using G          = WaveGeom<NQ, EC, 2>;
+    constexpr int NM = G::NM, NMP = G::NMP;
+
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *sb0 = lds, *sb1 = lds + G::NBAS;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *slab   = lds + 2 * G::NBAS + wib * G::SLAB;
+
+    for (int x = threadIdx.x; x < NM * NQ; x += kWave * WPB)
+    {
+        sb0[x] = b0[x];
+        sb1[x] = b1[x];
+    }
+    __syncthreads();
+    const double *bs0 = (BMODE == BASIS_SMEM) ? b0 : sb0;
+    const double *bs1 = (BMODE == BASIS_SMEM) ? b1 : sb1;
+
+    const uint64_t nchunk = (nelmt + EC - 1) / EC;
+    const uint64_t nwave  = (uint64_t)gridDim.x * WPB;
+    uint64_t c            = (uint64_t)blockIdx.x * WPB + wib;
+    if (c >= nchunk)
+        return;
+
+    double2_t st[G::NLD];
+    {
+        const uint64_t left = nelmt - c * EC;
+        if (left >= EC)
+            chunk_load<G, true>(st, in + c * G::IN_DBL, lane, 0);
+        else
+            chunk_load<G, false>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
+    }
+
+    for (; c < nchunk; c += nwave)
+    {
+        const uint64_t left = nelmt - c * EC;
+        const int evalid    = left >= EC ? EC : (int)left;
+
+        chunk_stage<G>(st, slab, lane);
+        wave_lds_fence();
+        {
+            const uint64_t cn = c + nwave;
+            if (cn < nchunk)
+            {
+                const uint64_t ln = nelmt - cn * EC;
+                if (ln >= EC)
+                    chunk_load<G, true>(st, in + cn * G::IN_DBL, lane, 0);
+                else
+                    chunk_load<G, false>(st, in + cn * G::IN_DBL, lane, (int)ln * G::NMT);
+            }
+        }
+        // ---- direction 0: w[(e,i)][q] = sum_p in[(e,q)][p] * B0[p][i] ---------------------------
+        {
+            double u[G::PASS0][NM], acc[G::PASS0][NQ];
+            read_pencils<NM, G::PASS0, G::P0, G::IN_STRIDE>(u, slab, lane);
+            contract<NM, NQ, G::PASS0, BMODE>(u, acc, bs0);
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < G::PASS0; ++s)
+            {
+                const int t = s * kWave + lane;
+                if ((s + 1) * kWave <= G::P0 || t < G::P0)
+                {
+                    const int e = t / NM, q = t - e * NM;
+                    double *dst = slab + e * NQ * NMP + q;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        dst[i * NMP] = acc[s][i];
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- direction 1: out[e][j][i] = sum_q w[(e,i)][q] * B1[q][j] ---------------------------
+        {
+            double u[G::PASS1][NM], acc[G::PASS1][NQ];
+            read_pencils<NM, G::PASS1, G::P1, NMP>(u, slab, lane);
+            contract<NM, NQ, G::PASS1, BMODE>(u, acc, bs1);
+            double *oc = out + c * (uint64_t)(EC * G::NQT);
+#pragma unroll
+            for (int s = 0; s < G::PASS1; ++s)
+            {
+                const int t = s * kWave + lane;
+                const int e = t / NQ, i = t - e * NQ;
+                if (((s + 1) * kWave <= G::P1 || t < G::P1) && e < evalid)
+                {
+                    double *dst = oc + e * G::NQT + i;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j)
+                        __builtin_nontemporal_store(acc[s][j], dst + j * NQ);
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+} // namespace sf

@@ -1,0 +1,252 @@
+// capi.hip -- the extern "C" boundary of libsumfact.so (declared in include/sumfact.h).
+// Validation + dispatch only; kernels live in bwdtrans_hex.hip / bwdtrans_quad.hip /
+// bwdtrans_generic.hip / aux_kernels.hip.
+#include "sf_common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace sf
+{
+int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
+int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
+int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
+                       hipStream_t s);
+int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);
+int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s);
+int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s);
+int fill_sincos(double *in, size_t nelmt, size_t nm_tot, hipStream_t s);
+int fill_basis(double *b, size_t nm, size_t nq, hipStream_t s);
+int fill_random(double *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
+int fill_l2norm(double *x, size_t n, hipStream_t s);
+int stream_copy(const double *src, double *dst, size_t n, hipStream_t s);
+int release_workspaces();
+} // namespace sf
+
+using namespace sf;
+
+static inline bool aligned(const void *p, size_t a)
+{
+    return ((uintptr_t)p & (a - 1)) == 0;
+}
+
+extern "C" {
+
+int sf_version(void)
+{
+    return SF_VERSION;
+}
+
+const char *sf_error_string(int rc)
+{
+    switch (rc)
+    {
+    case SF_OK: return "success";
+    case SF_EINVAL: return "invalid argument (nq < 2, null pointer, unknown variant or missing workspace)";
+    case SF_EALIGN: return "pointer not sufficiently aligned";
+    case SF_ENOTBUILT: return "variant not instantiated for these extents";
+    case SF_ENOMEM: return "internal workspace allocation failed";
+    default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "unknown sumfact error";
+    }
+}
+
+const char *sf_variant_name(int variant)
+{
+    static const char *names[SF_NUM_VARIANTS] = {"auto",      "wave",    "thread", "block-lds",
+                                                 "block-glb", "generic", "mfma"};
+    return (variant >= 0 && variant < SF_NUM_VARIANTS) ? names[variant] : "?";
+}
+
+int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
+                                size_t nelmt, const double *basis0, const double *basis1,
+                                const double *basis2, const double *in, double *wsp, double *out,
+                                void *stream)
+{
+    if (nq0 < 2 || nq1 < 2 || nq2 < 2 || variant < 0 || variant >= SF_NUM_VARIANTS)
+        return SF_EINVAL;
+    if (nelmt == 0)
+        return SF_OK;
+    if (!basis0 || !basis1 || !basis2 || !in || !out)
+        return SF_EINVAL;
+    if (!aligned(in, 8) || !aligned(out, 8) || !aligned(basis0, 8) || !aligned(basis1, 8) ||
+        !aligned(basis2, 8))
+        return SF_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    HexArgs a{basis0, basis1, basis2, in, wsp, out, (uint64_t)nelmt};
+    const bool iso = (nq0 == nq1 && nq1 == nq2);
+    // the wave kernels read `in` with 16-byte lanes
+    const bool vec_ok = aligned(in, 16);
+    switch (variant)
+    {
+    case SF_VARIANT_AUTO:
+    {
+        if (iso && vec_ok)
+        {
+            int rc = launch_hex_wave_nq(nq0, a, s);
+            if (rc != SF_ENOTBUILT)
+                return rc;
+        }
+        return launch_hex_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+    }
+    case SF_VARIANT_WAVE:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_hex_wave_nq(nq0, a, s);
+    case SF_VARIANT_GENERIC:
+        return launch_hex_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+    case SF_VARIANT_THREAD:
+    case SF_VARIANT_BLOCK_LDS:
+    case SF_VARIANT_BLOCK_GLB:
+        return launch_hex_generic(variant, nq0, nq1, nq2, a, s);
+    default:
+        return SF_ENOTBUILT;
+    }
+}
+
+int sf_bwdtrans_hex_f64(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                        const double *basis0, const double *basis1, const double *basis2,
+                        const double *in, double *out, void *stream)
+{
+    return sf_bwdtrans_hex_f64_variant(SF_VARIANT_AUTO, nq0, nq1, nq2, nelmt, basis0, basis1, basis2,
+                                       in, nullptr, out, stream);
+}
+
+int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t nelmt,
+                                 const double *basis0, const double *basis1, const double *in,
+                                 double *wsp, double *out, void *stream)
+{
+    if (nq0 < 2 || nq1 < 2 || variant < 0 || variant >= SF_NUM_VARIANTS)
+        return SF_EINVAL;
+    if (nelmt == 0)
+        return SF_OK;
+    if (!basis0 || !basis1 || !in || !out)
+        return SF_EINVAL;
+    if (!aligned(in, 8) || !aligned(out, 8) || !aligned(basis0, 8) || !aligned(basis1, 8))
+        return SF_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    QuadArgs a{basis0, basis1, in, wsp, out, (uint64_t)nelmt};
+    const bool iso    = (nq0 == nq1);
+    const bool vec_ok = aligned(in, 16);
+    switch (variant)
+    {
+    case SF_VARIANT_AUTO:
+    {
+        if (iso && vec_ok)
+        {
+            int rc = launch_quad_wave_nq(nq0, a, s);
+            if (rc != SF_ENOTBUILT)
+                return rc;
+        }
+        return launch_quad_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+    }
+    case SF_VARIANT_WAVE:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_quad_wave_nq(nq0, a, s);
+    case SF_VARIANT_GENERIC:
+        return launch_quad_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+    case SF_VARIANT_THREAD:
+    case SF_VARIANT_BLOCK_LDS:
+    case SF_VARIANT_BLOCK_GLB:
+        return launch_quad_generic(variant, nq0, nq1, a, s);
+    default:
+        return SF_ENOTBUILT;
+    }
+}
+
+int sf_bwdtrans_quad_f64(unsigned nq0, unsigned nq1, size_t nelmt, const double *basis0,
+                         const double *basis1, const double *in, double *out, void *stream)
+{
+    return sf_bwdtrans_quad_f64_variant(SF_VARIANT_AUTO, nq0, nq1, nelmt, basis0, basis1, in,
+                                        nullptr, out, stream);
+}
+
+int sf_sumsq_f64(const double *x, size_t n, double *result_host, void *stream)
+{
+    if (!result_host || (!x && n))
+        return SF_EINVAL;
+    if (n == 0)
+    {
+        *result_host = 0.0;
+        return SF_OK;
+    }
+    if (!aligned(x, 8))
+        return SF_EALIGN;
+    return sumsq_blocking(x, n, result_host, (hipStream_t)stream);
+}
+
+int sf_sumsq_f64_async(const double *x, size_t n, double *result_dev, void *stream)
+{
+    if (!result_dev || (!x && n))
+        return SF_EINVAL;
+    if (!aligned(x, 8))
+        return SF_EALIGN;
+    return sumsq_async(x, n, result_dev, (hipStream_t)stream);
+}
+
+int sf_fill_sincos_f64(double *in, size_t nelmt, size_t nm_tot, void *stream)
+{
+    if ((!in && nelmt * nm_tot) || nm_tot > 0xffffffffull)
+        return SF_EINVAL;
+    return fill_sincos(in, nelmt, nm_tot, (hipStream_t)stream);
+}
+
+int sf_fill_basis_f64(double *basis, size_t nm, size_t nq, void *stream)
+{
+    if ((!basis && nm * nq) || nm * nq > 0xffffffffull)
+        return SF_EINVAL;
+    return fill_basis(basis, nm, nq, (hipStream_t)stream);
+}
+
+int sf_fill_random_f64(double *x, size_t n, uint64_t seed, uint64_t first_idx, void *stream)
+{
+    if (!x && n)
+        return SF_EINVAL;
+    return fill_random(x, n, seed, first_idx, (hipStream_t)stream);
+}
+
+int sf_fill_l2norm_f64(double *x, size_t n, void *stream)
+{
+    if (!x && n)
+        return SF_EINVAL;
+    return fill_l2norm(x, n, (hipStream_t)stream);
+}
+
+int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream)
+{
+    if ((!src || !dst) && n)
+        return SF_EINVAL;
+    return stream_copy(src, dst, n, (hipStream_t)stream);
+}
+
+int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len)
+{
+    int dev      = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess)
+        return (int)e;
+    if (num_cu)
+        *num_cu = p.multiProcessorCount;
+    if (wave_size)
+        *wave_size = p.warpSize;
+    if (name && name_len)
+    {
+        std::snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return SF_OK;
+}
+
+int sf_shutdown(void)
+{
+    return release_workspaces();
+}
+
+} // extern "C"

@@ -1,0 +1,78 @@
+// wave_launch.h -- host-side launchers of the wave kernels (shared by the library and tools/sf_tune).
+#pragma once
+
+#include "bwdtrans_wave.h"
+
+namespace sf
+{
+
+constexpr int kMaxDev = 64;
+
+// Persistent grid: as many workgroups as the device keeps resident (occupancy query, cached per
+// device), never more than there are chunks.
+template <class K> inline int resident_blocks(K kern, int threads, size_t lds, int *cache)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDev)
+        dev = 0;
+    if (cache[dev] == 0)
+    {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)kern,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int bpc = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, threads, lds) != hipSuccess ||
+            bpc < 1)
+        {
+            (void)hipGetLastError();
+            bpc = 1;
+        }
+        cache[dev] = bpc;
+    }
+    return cache[dev] * device_info().num_cu;
+}
+
+template <int NQ, int EC, int WPB, int BMODE, int MINW>
+inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 0)
+{
+    static int cache[kMaxDev] = {};
+    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB>();
+    static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
+    const uint64_t need   = (nchunk + WPB - 1) / WPB;
+    uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
+    if (grid_override > 0)
+        grid = (uint64_t)grid_override;
+    if (grid > need)
+        grid = need;
+    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+template <int NQ, int EC, int WPB, int BMODE, int MINW>
+inline int launch_quad_wave(const QuadArgs &a, hipStream_t s, int grid_override = 0)
+{
+    static int cache[kMaxDev] = {};
+    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB>();
+    static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
+    const uint64_t need   = (nchunk + WPB - 1) / WPB;
+    uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
+    if (grid_override > 0)
+        grid = (uint64_t)grid_override;
+    if (grid > need)
+        grid = need;
+    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+} // namespace sf

@@ -1,0 +1,132 @@
+/*
+ * include/sumfact.h -- C ABI of libsumfact.so, the MI355X (gfx950) drop-in for the BwdTrans
+ * sum-factorisation hot path of CFD-Xing/gpu-benchmarking.
+ *
+ * The reference has no FFI: its "interface" for this path is the kernel call a maintainer makes from
+ * run_test<T> (benchmark05/benchmark05.cc:1322-1328, benchmark04/benchmark04.cc:1001-1004): raw
+ * device pointers + unsigned extents, caller owns every buffer, the kernel allocates nothing.  Each
+ * entry point below replaces one such call site (cited per function).  INTEGRATION.md shows the
+ * exact edit in the reference's run_test.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - layouts are the reference's: in[e][r][q][p] (p fastest), out[e][k][j][i] (i fastest),
+ *     basis[p*nq + i] row-major nm x nq, nm = nq - 1;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream, as in the reference);
+ *     launches are asynchronous, like a <<<>>> launch; the caller synchronises;
+ *   - element counts are size_t (the reference's 32-bit `unsigned` overflows at
+ *     nelmt*nq^3 > 2^32, i.e. above 8 388 608 elements at nq = 8);
+ *   - return value: 0 on success, a positive hipError_t, or a negative SF_E* code.  The reference
+ *     reports no errors at all; nothing here aborts the process.
+ */
+#ifndef SUMFACT_H
+#define SUMFACT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_VERSION 100
+
+enum
+{
+    SF_OK        = 0,
+    SF_EINVAL    = -1, /* nq < 2, null pointer with nelmt > 0, unknown variant */
+    SF_EALIGN    = -2, /* in/out not 8-byte aligned */
+    SF_ENOTBUILT = -3, /* requested variant has no instantiation for this nq */
+    SF_ENOMEM    = -4  /* internal workspace allocation failed */
+};
+
+/* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest known. */
+enum
+{
+    SF_VARIANT_AUTO       = 0,
+    SF_VARIANT_WAVE       = 1, /* flagship: one wavefront streams chunks of elements, LDS-staged */
+    SF_VARIANT_THREAD     = 2, /* one thread per element, fused nest  (cf. benchmark05.cc:15-102)  */
+    SF_VARIANT_BLOCK_LDS  = 3, /* one workgroup per element, 3 sweeps in LDS (cf. :291-429)       */
+    SF_VARIANT_BLOCK_GLB  = 4, /* one workgroup per element, global workspace (cf. :203-289)       */
+    SF_VARIANT_GENERIC    = 5, /* runtime-nq fallback (anisotropic nq0 != nq1 != nq2)              */
+    SF_VARIANT_MFMA       = 6, /* wave kernel with v_mfma_f64_16x16x4 sweeps (high order)          */
+    SF_NUM_VARIANTS       = 7
+};
+
+int sf_version(void);
+const char *sf_error_string(int rc);
+const char *sf_variant_name(int variant);
+
+/*
+ * 3D hex BwdTrans: out[e][k][j][i] = sum_r sum_q sum_p in[e][r][q][p] B0[p][i] B1[q][j] B2[r][k].
+ * Replaces BwdTransHexKernel_QP<<<blocks, dim3(...), smem>>>(nm0,nm1,nm2,nmTot,nq0,nq1,nq2,nelmt,
+ * d_basis0,d_basis1,d_basis2,d_in,d_out)  -- benchmark05/benchmark05.cc:1322-1328 (and the other
+ * five launches :1265, :1283, :1300, :1342, :1362, which compute the same result).
+ */
+int sf_bwdtrans_hex_f64(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                        const double *basis0, const double *basis1, const double *basis2,
+                        const double *in, double *out, void *stream);
+
+/* Same, with an explicit strategy; wsp (may be NULL) is only used by SF_VARIANT_BLOCK_GLB and
+ * must then hold nelmt*(nq0*nm1*nm2 + nq0*nq1*nm2) doubles (benchmark05.cc:1243-1244). */
+int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
+                                size_t nelmt, const double *basis0, const double *basis1,
+                                const double *basis2, const double *in, double *wsp, double *out,
+                                void *stream);
+
+/*
+ * 2D quad BwdTrans: out[e][j][i] = sum_q sum_p in[e][q][p] B0[p][i] B1[q][j].
+ * Replaces BwdTransQuadKernel_QP_1D<<<blocks, threads, smem>>>(nm0,nm1,nmTot,nq0,nq1,nelmt,
+ * d_basis0,d_basis1,d_in,d_out) -- benchmark04/benchmark04.cc:1001-1004 (and :912, :930, :947,
+ * :966, :983).
+ */
+int sf_bwdtrans_quad_f64(unsigned nq0, unsigned nq1, size_t nelmt, const double *basis0,
+                         const double *basis1, const double *in, double *out, void *stream);
+
+int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t nelmt,
+                                 const double *basis0, const double *basis1, const double *in,
+                                 double *wsp, double *out, void *stream);
+
+/*
+ * sum_i x[i]^2 -> *result_host (blocking: synchronises `stream`).  Deterministic (fixed-shape
+ * two-pass tree).  Replaces thrust::transform_reduce(d_out, d_out + n, x*x, 0, plus)
+ * -- benchmark05/benchmark05.cc:1273-1276 -- and bm01's l2norm kernels
+ * (benchmark01/benchmark01.cc:245-253).
+ */
+int sf_sumsq_f64(const double *x, size_t n, double *result_host, void *stream);
+
+/* Same reduction, result left on the device (result_dev[0]); asynchronous. */
+int sf_sumsq_f64_async(const double *x, size_t n, double *result_dev, void *stream);
+
+/*
+ * Device-side initialisers (the reference fills on the host and copies:
+ * benchmark05/benchmark05.cc:1195-1258).
+ *   sincos : in[e*nm_tot + f] = sin(f + 1)                      (:1206-1207)
+ *   basis  : basis[x] = cos(x), x < nm*nq                        (:1220)
+ *   random : x[i] = U[-1,1) from splitmix64(seed, first_idx + i) (not in the reference; identical
+ *            to oracle_fill_random so host and device arrays agree bit for bit)
+ *   l2norm : x[i] = i%13 + (0.2 + 1e-5*(i%100191))              (benchmark01/benchmark01.cc:178)
+ * sin/cos run on the device's libm: values may differ from glibc's in the last ulp.
+ */
+int sf_fill_sincos_f64(double *in, size_t nelmt, size_t nm_tot, void *stream);
+int sf_fill_basis_f64(double *basis, size_t nm, size_t nq, void *stream);
+int sf_fill_random_f64(double *x, size_t n, uint64_t seed, uint64_t first_idx, void *stream);
+int sf_fill_l2norm_f64(double *x, size_t n, void *stream);
+
+/*
+ * HBM calibrators (benchmark02/benchmark02.cc:16-58 is the reference's analogue):
+ * dst[i] = src[i] with 16-byte lanes, n doubles.  Used to report the *measured* stream rate next
+ * to the 8 TB/s datasheet roofline.
+ */
+int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream);
+
+/* Number of compute units / device name of the current device (for logs). */
+int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len);
+
+/* Free internal workspaces of the current device (optional; called at exit otherwise never). */
+int sf_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMFACT_H */

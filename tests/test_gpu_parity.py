@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP path (through the C ABI of libsumfact.so) against the CPU oracle.
+
+Bar: fp64, max|GPU - oracle| / max|oracle| <= 1e-12 (BASELINE.json north_star), on per-element-
+distinct seeded data (catches element-offset bugs that the reference's identical data hides) and on
+the reference's sin/cos data (golden `norm:` values of the committed logs, 10 digits).
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def sf():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    return torch
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _hex_case(sf, oracle, nq, nelmt, variant, seed=1):
+    nm = [q - 1 for q in nq]
+    bs = [sf.fill_random(nm[d] * nq[d], 100 + d + seed) for d in range(3)]
+    x = sf.fill_random(nelmt * nm[0] * nm[1] * nm[2], seed)
+    out = sf.bwdtrans_hex(nq, *bs, x, variant=variant)
+    ref = oracle.bwdtrans_hex(tuple(nq), nelmt, *[_np(b) for b in bs], _np(x))
+    return oracle.rel_err(_np(out), ref)
+
+
+def _quad_case(sf, oracle, nq, nelmt, variant, seed=1):
+    nm = [q - 1 for q in nq]
+    bs = [sf.fill_random(nm[d] * nq[d], 200 + d + seed) for d in range(2)]
+    x = sf.fill_random(nelmt * nm[0] * nm[1], seed)
+    out = sf.bwdtrans_quad(nq, *bs, x, variant=variant)
+    ref = oracle.bwdtrans_quad(tuple(nq), nelmt, *[_np(b) for b in bs], _np(x))
+    return oracle.rel_err(_np(out), ref)
+
+
+# ragged element counts: 1, below / at / above every chunk size, primes
+RAGGED = [1, 2, 3, 5, 13, 14, 15, 63, 64, 65, 127, 257, 1000, 4099]
+
+
+@pytest.mark.parametrize("nq", range(2, 11))
+def test_hex_wave_parity_all_orders(sf, oracle, nq):
+    for nelmt in RAGGED:
+        err = _hex_case(sf, oracle, (nq,) * 3, nelmt, "wave", seed=nelmt)
+        assert err <= TOL, (nq, nelmt, err)
+
+
+@pytest.mark.parametrize("nq", list(range(2, 17)) + [32])
+def test_quad_wave_parity_all_orders(sf, oracle, nq):
+    for nelmt in RAGGED:
+        err = _quad_case(sf, oracle, (nq, nq), nelmt, "wave", seed=nelmt)
+        assert err <= TOL, (nq, nelmt, err)
+
+
+@pytest.mark.parametrize("variant", ["auto", "thread", "block-lds", "block-glb", "generic"])
+def test_hex_variants(sf, oracle, variant):
+    for nq in [(2, 2, 2), (4, 4, 4), (8, 8, 8), (3, 5, 4), (8, 2, 6), (10, 10, 10), (12, 12, 12)]:
+        for nelmt in (1, 7, 130):
+            err = _hex_case(sf, oracle, nq, nelmt, variant)
+            assert err <= TOL, (variant, nq, nelmt, err)
+
+
+@pytest.mark.parametrize("variant", ["auto", "thread", "block-lds", "block-glb", "generic"])
+def test_quad_variants(sf, oracle, variant):
+    for nq in [(2, 2), (8, 8), (4, 9), (16, 3), (20, 20), (32, 32), (40, 40)]:
+        for nelmt in (1, 9, 300):
+            err = _quad_case(sf, oracle, nq, nelmt, variant)
+            assert err <= TOL, (variant, nq, nelmt, err)
+
+
+def test_golden_norms_hex(sf, golden):
+    """Reference sin/cos data -> sqrt(sum out^2) equals the `norm:` column of the committed logs."""
+    for nq_s, entry in golden["hex"].items():
+        nq = int(nq_s)
+        nm = nq - 1
+        b = sf.fill_basis(nm, nq)
+        for row in entry["rows"]:
+            n = row["n"]
+            if n not in (128, 4096, 1048576):
+                continue
+            x = sf.fill_sincos(n, nm ** 3)
+            out = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+            norm = math.sqrt(sf.sumsq(out))
+            ref = float(row["norm"])
+            assert abs(norm - ref) <= 5.5e-10 * ref, (entry["file"], row, norm)
+            del x, out
+
+
+def test_golden_norms_quad(sf, golden):
+    for nq_s, entry in golden["quad"].items():
+        nq = int(nq_s)
+        nm = nq - 1
+        b = sf.fill_basis(nm, nq)
+        for row in entry["rows"]:
+            n = row["n"]
+            if n not in (128, 4096, 1048576):
+                continue
+            x = sf.fill_sincos(n, nm * nm)
+            out = sf.bwdtrans_quad((nq, nq), b, b, x)
+            norm = math.sqrt(sf.sumsq(out))
+            ref = float(row["norm"])
+            assert abs(norm - ref) <= 5.5e-10 * ref, (entry["file"], row, norm)
+
+
+def test_golden_norms_l2norm(sf, golden):
+    """bm01 data + sum of squares on the device, all 20 sizes (up to 536 870 912 doubles)."""
+    for row in golden["l2norm"]["rows"]:
+        x = sf.fill_l2norm(row["n"])
+        norm = math.sqrt(sf.sumsq(x))
+        ref = float(row["norm"])
+        assert abs(norm - ref) <= 5.5e-10 * ref, (row, norm)
+        del x
+
+
+def test_fills_match_oracle(sf, oracle):
+    a = _np(sf.fill_random(100003, 0x5F3759DF, 12345))
+    assert np.array_equal(a, oracle.fill_random(100003, 0x5F3759DF, 12345))  # bit-exact
+    s = _np(sf.fill_sincos(5, 343))
+    assert np.max(np.abs(s - oracle.fill_sincos(5, 343))) <= 4e-16          # device libm: <= 2 ulp
+    b = _np(sf.fill_basis(7, 8))
+    assert np.max(np.abs(b - oracle.fill_basis(7, 8))) <= 4e-16
+    x = _np(sf.fill_l2norm(300000))
+    assert np.array_equal(x, oracle.fill_l2norm(300000))
+
+
+def test_sumsq(sf, oracle, torch_mod):
+    for n in (1, 2, 3, 255, 4096, 1000003):
+        x = sf.fill_random(n, 9)
+        got = sf.sumsq(x)
+        ref = oracle.sumsq(_np(x))
+        assert abs(got - ref) <= 1e-13 * ref, (n, got, ref)
+        assert got == sf.sumsq(x)  # deterministic
+    # unaligned view (8-byte aligned only)
+    x = sf.fill_random(1001, 3)
+    assert abs(sf.sumsq(x[1:]) - oracle.sumsq(_np(x)[1:])) <= 1e-13 * 400
+
+
+def test_empty_and_errors(sf, torch_mod):
+    capi = sf.capi
+    b = sf.fill_basis(7, 8)
+    empty = torch_mod.empty(0, dtype=torch_mod.float64, device="cuda")
+    assert sf.bwdtrans_hex((8, 8, 8), b, b, b, empty).numel() == 0
+    assert sf.bwdtrans_quad((8, 8), b, b, empty).numel() == 0
+    with pytest.raises(capi.SumfactError) as ei:
+        sf.bwdtrans_hex((1, 8, 8), b, b, b, empty)
+    assert ei.value.rc == capi.SF_EINVAL
+    x = sf.fill_random(343 * 4, 1)
+    with pytest.raises(capi.SumfactError) as ei:
+        sf.bwdtrans_hex((8, 8, 8), b, b, b, x, variant="mfma" if False else 6)
+    assert ei.value.rc in (capi.SF_ENOTBUILT, capi.SF_OK)
+
+
+def test_unaligned_input_falls_back(sf, oracle):
+    """`in` only 8-byte aligned: AUTO must still be correct (generic path), WAVE refuses."""
+    nq, nelmt = 8, 11
+    b = sf.fill_basis(7, 8)
+    buf = sf.fill_random(nelmt * 343 + 1, 5)
+    x = buf[1:]
+    out = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+    ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, _np(b), _np(b), _np(b), _np(x))
+    assert oracle.rel_err(_np(out), ref) <= TOL
+    with pytest.raises(sf.capi.SumfactError) as ei:
+        sf.bwdtrans_hex((nq,) * 3, b, b, b, x, variant="wave")
+    assert ei.value.rc == sf.capi.SF_EALIGN
+
+
+def test_hex_linearity_and_idempotence_full_size(sf, torch_mod):
+    """BASELINE full size (1 048 576 elements, nq=8): properties that need no CPU reference:
+    T(a*x + y) == a*T(x) + T(y) to rounding, and two runs are bit-identical."""
+    nq, nelmt = 8, 1 << 20
+    nm = nq - 1
+    b = sf.fill_basis(nm, nq)
+    x = sf.fill_random(nelmt * nm ** 3, 11)
+    y = sf.fill_random(nelmt * nm ** 3, 12)
+    tx = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+    ty = sf.bwdtrans_hex((nq,) * 3, b, b, b, y)
+    z = 0.5 * x + y
+    tz = sf.bwdtrans_hex((nq,) * 3, b, b, b, z)
+    lin = 0.5 * tx + ty
+    err = float((tz - lin).abs().max() / lin.abs().max())
+    assert err <= TOL, err
+    tx2 = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+    assert torch_mod.equal(tx, tx2)
+
+
+def test_hex_64bit_indexing(sf, oracle, torch_mod):
+    """More than 2^32 output doubles (the reference's `unsigned` index overflows above 8 388 608
+    elements at nq=8): check the tail elements against the oracle and a checksum identity."""
+    nq, nelmt = 8, 8388608 + 1030
+    nm = nq - 1
+    free, _ = torch_mod.cuda.mem_get_info()
+    need = 8 * nelmt * (nm ** 3 + nq ** 3) + (1 << 30)
+    if free < need:
+        pytest.skip("not enough device memory")
+    b = sf.fill_basis(nm, nq)
+    x = sf.fill_random(nelmt * nm ** 3, 77)
+    out = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+    tail = 1500
+    xt = _np(x[(nelmt - tail) * nm ** 3:])
+    ref = oracle.bwdtrans_hex((nq,) * 3, tail, _np(b), _np(b), _np(b), xt)
+    got = _np(out[(nelmt - tail) * nq ** 3:])
+    assert oracle.rel_err(got, ref) <= TOL
+    # head too
+    ref0 = oracle.bwdtrans_hex((nq,) * 3, 64, _np(b), _np(b), _np(b), _np(x[:64 * nm ** 3]))
+    assert oracle.rel_err(_np(out[:64 * nq ** 3]), ref0) <= TOL
+    # sin/cos data: every element identical -> sum of squares = nelmt * one element's
+    del x, out
+    x = sf.fill_sincos(nelmt, nm ** 3)
+    out = sf.bwdtrans_hex((nq,) * 3, b, b, b, x)
+    ss = sf.sumsq(out)
+    ss1 = sf.sumsq(out[:nq ** 3])
+    assert abs(ss - nelmt * ss1) <= 1e-11 * ss
