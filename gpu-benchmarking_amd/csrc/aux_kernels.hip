@@ -55,11 +55,13 @@ __global__ __launch_bounds__(256) void fill_random_kernel(double *__restrict__ x
 
 __global__ __launch_bounds__(256) void fill_l2norm_kernel(double *__restrict__ x, uint64_t n)
 {
+#pragma clang fp contract(off) // same roundings as the host statement (no FMA): bit-exact
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     {
         const uint32_t u = (uint32_t)i;
-        x[i]             = u % 13u + (0.2 + 0.00001 * (u % 100191u));
+        const double t   = 0.00001 * (double)(u % 100191u);
+        x[i]             = (double)(u % 13u) + (0.2 + t);
     }
 }
 

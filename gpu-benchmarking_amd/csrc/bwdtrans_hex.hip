@@ -6,22 +6,23 @@
 namespace sf
 {
 
-// NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD
+// NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
+// (0 = persistent), 16-byte stores
 template <int NQ> struct HexCfg;
-template <> struct HexCfg<2>  { static constexpr int EC = 64, WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<3>  { static constexpr int EC = 14, WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<4>  { static constexpr int EC = 8,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<5>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<6>  { static constexpr int EC = 6,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<7>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<8>  { static constexpr int EC = 2,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<9>  { static constexpr int EC = 3,  WPB = 4, BM = BASIS_LDS, MW = 2; };
-template <> struct HexCfg<10> { static constexpr int EC = 2,  WPB = 4, BM = BASIS_LDS, MW = 2; };
+template <> struct HexCfg<2>  { static constexpr int EC = 64, WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<3>  { static constexpr int EC = 14, WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<4>  { static constexpr int EC = 8,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<5>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<6>  { static constexpr int EC = 6,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<7>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<8>  { static constexpr int EC = 2,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<9>  { static constexpr int EC = 3,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+template <> struct HexCfg<10> { static constexpr int EC = 2,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
 
 template <int NQ> static int go(const HexArgs &a, hipStream_t s)
 {
     using C = HexCfg<NQ>;
-    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW>(a, s);
+    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16 && (NQ % 2 == 0)>(a, s);
 }
 
 // returns SF_ENOTBUILT when nq has no instantiation

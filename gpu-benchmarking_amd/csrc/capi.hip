@@ -74,8 +74,8 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
     hipStream_t s = (hipStream_t)stream;
     HexArgs a{basis0, basis1, basis2, in, wsp, out, (uint64_t)nelmt};
     const bool iso = (nq0 == nq1 && nq1 == nq2);
-    // the wave kernels read `in` with 16-byte lanes
-    const bool vec_ok = aligned(in, 16);
+    // the wave kernels read `in` and write `out` with 16-byte lanes
+    const bool vec_ok = aligned(in, 16) && aligned(out, 16);
     switch (variant)
     {
     case SF_VARIANT_AUTO:
@@ -128,7 +128,7 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
     hipStream_t s = (hipStream_t)stream;
     QuadArgs a{basis0, basis1, in, wsp, out, (uint64_t)nelmt};
     const bool iso    = (nq0 == nq1);
-    const bool vec_ok = aligned(in, 16);
+    const bool vec_ok = aligned(in, 16) && aligned(out, 16);
     switch (variant)
     {
     case SF_VARIANT_AUTO:

@@ -33,43 +33,49 @@ template <class K> inline int resident_blocks(K kern, int threads, size_t lds, i
     return cache[dev] * device_info().num_cu;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, bool ST16 = false>
 inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB>();
+    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, ST16>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t need   = (nchunk + WPB - 1) / WPB;
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need)
+    if (grid > need || KMAP > 0)
         grid = need;
+    if (grid > 0x7fffffffull)
+        return SF_EINVAL;
     kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, bool ST16 = false>
 inline int launch_quad_wave(const QuadArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB>();
+    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, ST16>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t need   = (nchunk + WPB - 1) / WPB;
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need)
+    if (grid > need || KMAP > 0)
         grid = need;
+    if (grid > 0x7fffffffull)
+        return SF_EINVAL;
     kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SF_OK : (int)e;

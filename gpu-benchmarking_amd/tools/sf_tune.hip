@@ -68,27 +68,27 @@ struct Bench
     }
 };
 
-template <int NQ, int EC, int WPB, int BM, int MW>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM = 0, bool S16 = false>
 void hex_case(Bench &b, const HexArgs &a, int grid = 0)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d g%d", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, grid);
+    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s g%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, S16 ? "st16" : "st8 ", grid);
     const double nm = NQ - 1;
     b.run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ),
           a.out, a.nelmt * (size_t)NQ * NQ * NQ,
-          [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW>(a, 0, grid); });
+          [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, S16>(a, 0, grid); });
 }
 
-template <int NQ, int EC, int WPB, int BM, int MW>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM = 0, bool S16 = false>
 void quad_case(Bench &b, const QuadArgs &a, int grid = 0)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad nq%d EC%d WPB%d %s MW%d g%d", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, grid);
+    std::snprintf(label, sizeof label, "quad nq%d EC%d WPB%d %s MW%d K%d %s g%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, S16 ? "st16" : "st8 ", grid);
     const double nm = NQ - 1;
     b.run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
-          a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW>(a, 0, grid); });
+          a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, S16>(a, 0, grid); });
 }
 
 int main(int argc, char **argv)
@@ -133,21 +133,24 @@ int main(int argc, char **argv)
         HexArgs a{b0, b1, b2, in, nullptr, out, nelmt};
         if (nq == 8)
         {
-            hex_case<8, 2, 4, BASIS_LDS, 2>(b, a);
-            hex_case<8, 2, 4, BASIS_LDS, 3>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 2>(b, a);
             hex_case<8, 2, 4, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 2, 2, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 2, 8, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 2, 1, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 1, 4, BASIS_LDS, 4>(b, a);
-            hex_case<8, 1, 4, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 1, 4, BASIS_SMEM, 6>(b, a);
-            hex_case<8, 4, 4, BASIS_LDS, 2>(b, a);
-            hex_case<8, 4, 4, BASIS_SMEM, 2>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4>(b, a, 256);
-            hex_case<8, 2, 4, BASIS_SMEM, 4>(b, a, 512);
-            hex_case<8, 2, 4, BASIS_SMEM, 4>(b, a, 2048);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a);
+            hex_case<8, 2, 4, BASIS_LDS, 2, 0, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 1, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 2, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 4, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 8, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 16, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 64, true>(b, a);
+            hex_case<8, 2, 2, BASIS_SMEM, 4, 4, true>(b, a);
+            hex_case<8, 2, 1, BASIS_SMEM, 4, 4, true>(b, a);
+            hex_case<8, 2, 8, BASIS_SMEM, 4, 4, true>(b, a);
+            hex_case<8, 1, 4, BASIS_SMEM, 4, 8, false>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 0, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 4, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a, 768);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a, 2560);
         }
         else if (nq == 2) { hex_case<2, 64, 4, BASIS_LDS, 2>(b, a); hex_case<2, 64, 4, BASIS_SMEM, 2>(b, a); hex_case<2, 128, 4, BASIS_SMEM, 2>(b, a); }
         else if (nq == 3) { hex_case<3, 14, 4, BASIS_LDS, 2>(b, a); hex_case<3, 14, 4, BASIS_SMEM, 2>(b, a); hex_case<3, 28, 4, BASIS_SMEM, 2>(b, a); }
@@ -163,10 +166,10 @@ int main(int argc, char **argv)
         QuadArgs a{b0, b1, in, nullptr, out, nelmt};
         if (nq == 8)
         {
-            quad_case<8, 16, 4, BASIS_LDS, 2>(b, a);
             quad_case<8, 16, 4, BASIS_SMEM, 2>(b, a);
-            quad_case<8, 8, 4, BASIS_SMEM, 4>(b, a);
-            quad_case<8, 32, 4, BASIS_SMEM, 2>(b, a);
+            quad_case<8, 16, 4, BASIS_SMEM, 2, 0, true>(b, a);
+            quad_case<8, 16, 4, BASIS_SMEM, 2, 4, true>(b, a);
+            quad_case<8, 32, 4, BASIS_SMEM, 2, 4, true>(b, a);
         }
     }
     return 0;
