@@ -9,20 +9,28 @@ namespace sf
 // NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
 // (0 = persistent), 16-byte stores
 template <int NQ> struct HexCfg;
-template <> struct HexCfg<2>  { static constexpr int EC = 64, WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<3>  { static constexpr int EC = 14, WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<4>  { static constexpr int EC = 8,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<5>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<6>  { static constexpr int EC = 6,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<7>  { static constexpr int EC = 5,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<8>  { static constexpr int EC = 2,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<9>  { static constexpr int EC = 3,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
-template <> struct HexCfg<10> { static constexpr int EC = 2,  WPB = 4, BM = BASIS_SMEM, MW = 2, KM = 0; static constexpr bool S16 = false; };
+#define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, S16_)                                            \
+    template <> struct HexCfg<NQ_>                                                                 \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_;                   \
+        static constexpr bool S16 = S16_;                                                          \
+    }
+//          nq  EC  WPB  basis       MINW KMAP st16
+SF_HEX_CFG(2,  64, 4, BASIS_SMEM, 2, 2, true);
+SF_HEX_CFG(3,  14, 4, BASIS_SMEM, 2, 2, false);
+SF_HEX_CFG(4,  8,  4, BASIS_SMEM, 2, 2, true);
+SF_HEX_CFG(5,  5,  4, BASIS_SMEM, 2, 2, false);
+SF_HEX_CFG(6,  6,  4, BASIS_SMEM, 2, 2, true);
+SF_HEX_CFG(7,  5,  4, BASIS_SMEM, 2, 2, false);
+SF_HEX_CFG(8,  4,  4, BASIS_SMEM, 2, 2, true); // 302 GDOF/s min / 287 mean @1Mi (tune8c.log)
+SF_HEX_CFG(9,  2,  4, BASIS_SMEM, 2, 2, false);
+SF_HEX_CFG(10, 2,  4, BASIS_SMEM, 2, 2, true);
+#undef SF_HEX_CFG
 
 template <int NQ> static int go(const HexArgs &a, hipStream_t s)
 {
     using C = HexCfg<NQ>;
-    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16 && (NQ % 2 == 0)>(a, s);
+    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16>(a, s);
 }
 
 // returns SF_ENOTBUILT when nq has no instantiation

@@ -12,14 +12,16 @@ template <int NQ> struct QuadCfg
     static constexpr int EC0 = (NQ <= 10) ? 2 * PER : PER;
     // chunk must hold an even number of doubles for the 16-byte loads
     static constexpr int EC  = ((EC0 * (NQ - 1) * (NQ - 1)) % 2 == 0) ? EC0 : EC0 + 1;
-    static constexpr int WPB = 4, BM = BASIS_SMEM, MW = (NQ <= 16) ? 2 : 1, KM = 0;
-    static constexpr bool S16 = false;
+    // scalar-operand rows need 2*NQ SGPRs each (ring of 3): beyond nq ~ 10 they spill -> LDS copy
+    static constexpr int WPB = 4, BM = (NQ <= 10) ? BASIS_SMEM : BASIS_LDS, MW = (NQ <= 16) ? 2 : 1,
+                         KM = 2;
+    static constexpr bool S16 = (NQ % 2 == 0);
 };
 
 template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
 {
     using C = QuadCfg<NQ>;
-    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16 && (NQ % 2 == 0)>(a, s);
+    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16>(a, s);
 }
 
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

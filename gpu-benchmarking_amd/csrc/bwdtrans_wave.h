@@ -114,7 +114,7 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
 // ------------------------------------------------------------------------------------------------
 // chunk load: global -> staging registers (issued one chunk ahead of its use)
 // ------------------------------------------------------------------------------------------------
-template <class G, bool FULL>
+template <class G, bool FULL, bool NTL = true>
 __device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double *__restrict__ src,
                                            int lane, int nvalid /*doubles, only if !FULL*/)
 {
@@ -128,15 +128,15 @@ __device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double
             if constexpr (FULL)
             {
                 if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
-                    st[k] = __builtin_nontemporal_load(src2 + v);
+                    st[k] = NTL ? __builtin_nontemporal_load(src2 + v) : src2[v];
             }
             else
             {
                 double2_t x = {0.0, 0.0};
                 if (2 * v + 1 < nvalid)
-                    x = __builtin_nontemporal_load(src2 + v);
+                    x = NTL ? __builtin_nontemporal_load(src2 + v) : src2[v];
                 else if (2 * v < nvalid)
-                    x.x = __builtin_nontemporal_load(src + 2 * v);
+                    x.x = NTL ? __builtin_nontemporal_load(src + 2 * v) : src[2 * v];
                 st[k] = x;
             }
         }
@@ -149,7 +149,7 @@ __device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double
             const int v = k * kWave + lane;
             double x    = 0.0;
             if (v < (FULL ? G::IN_DBL : nvalid))
-                x = __builtin_nontemporal_load(src + v);
+                x = NTL ? __builtin_nontemporal_load(src + v) : src[v];
             st[k].x = x;
         }
     }
@@ -297,20 +297,20 @@ __device__ __forceinline__ double *wave_setup(double *lds, const double *const (
     }
 }
 
-template <class G, int EC>
+template <class G, int EC, bool NTL = true>
 __device__ __forceinline__ void chunk_fetch(double2_t (&st)[G::NLD], const double *__restrict__ in,
                                             uint64_t c, uint64_t nelmt, int lane)
 {
     const uint64_t left = nelmt - c * EC;
     if (left >= EC)
-        chunk_load<G, true>(st, in + c * G::IN_DBL, lane, 0);
+        chunk_load<G, true, NTL>(st, in + c * G::IN_DBL, lane, 0);
     else
-        chunk_load<G, false>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
+        chunk_load<G, false, NTL>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
 }
 
 // Final-sweep store of one pass: lane t owns NOUT values acc[n] destined for dst[n*NSTRIDE]
 // (consecutive lanes -> consecutive doubles).  ST16: lane pairs exchange so each lane stores 16 B.
-template <int NOUT, int NSTRIDE, bool ST16>
+template <int NOUT, int NSTRIDE, bool ST16, bool NTS = true>
 __device__ __forceinline__ void store_column(const double (&acc)[NOUT], double *dst, int lane)
 {
     if constexpr (ST16)
@@ -326,21 +326,29 @@ __device__ __forceinline__ void store_column(const double (&acc)[NOUT], double *
             double2_t v;
             v.x = odd ? got : acc[n];
             v.y = odd ? acc[n + 1] : got;
-            __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(d2 + n * NSTRIDE));
+            if (NTS)
+                __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(d2 + n * NSTRIDE));
+            else
+                *reinterpret_cast<double2_t *>(d2 + n * NSTRIDE) = v;
         }
     }
     else
     {
 #pragma unroll
         for (int n = 0; n < NOUT; ++n)
-            __builtin_nontemporal_store(acc[n], dst + n * NSTRIDE);
+        {
+            if (NTS)
+                __builtin_nontemporal_store(acc[n], dst + n * NSTRIDE);
+            else
+                dst[n * NSTRIDE] = acc[n];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // 3D hex
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16, int MEMF = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
     const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         return;
 
     double2_t st[G::NLD];
-    chunk_fetch<G, EC>(st, in, it.first, nelmt, lane);
+    chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         // request the next chunk of this wave now; it lands in the staging registers while this
         // chunk is being computed
         if (n + 1 < it.count)
-            chunk_fetch<G, EC>(st, in, c + it.step, nelmt, lane);
+            chunk_fetch<G, EC, !(MEMF & 1)>(st, in, c + it.step, nelmt, lane);
 
         // ---- direction 0: w1[(e,i,r)][q] = sum_p in[(e,r,q)][p] * B0[p][i] ----------------------
         {
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
                 const int t = s * kWave + lane;
                 const int e = t / NQ2, pl = t - e * NQ2;
                 if (((s + 1) * kWave <= G::P2 || t < G::P2) && e < evalid)
-                    store_column<NQ, NQ2, ST16>(acc[s], oc + e * G::NQT + pl, lane);
+                    store_column<NQ, NQ2, ST16, !(MEMF & 2)>(acc[s], oc + e * G::NQT + pl, lane);
             }
             wave_lds_fence(); // slab is rewritten by the next chunk's staging
         }
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
 // ------------------------------------------------------------------------------------------------
 // 2D quad
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16, int MEMF = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
         return;
 
     double2_t st[G::NLD];
-    chunk_fetch<G, EC>(st, in, it.first, nelmt, lane);
+    chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
         chunk_stage<G>(st, slab, lane);
         wave_lds_fence();
         if (n + 1 < it.count)
-            chunk_fetch<G, EC>(st, in, c + it.step, nelmt, lane);
+            chunk_fetch<G, EC, !(MEMF & 1)>(st, in, c + it.step, nelmt, lane);
 
         // ---- direction 0: w[(e,i)][q] = sum_p in[(e,q)][p] * B0[p][i] ---------------------------
         {
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
                 const int t = s * kWave + lane;
                 const int e = t / NQ, i = t - e * NQ;
                 if (((s + 1) * kWave <= G::P1 || t < G::P1) && e < evalid)
-                    store_column<NQ, NQ, ST16>(acc[s], oc + e * G::NQT + i, lane);
+                    store_column<NQ, NQ, ST16, !(MEMF & 2)>(acc[s], oc + e * G::NQT + i, lane);
             }
             wave_lds_fence();
         }

@@ -68,16 +68,16 @@ struct Bench
     }
 };
 
-template <int NQ, int EC, int WPB, int BM, int MW, int KM = 0, bool S16 = false>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM = 0, bool S16 = false, int MF = 0>
 void hex_case(Bench &b, const HexArgs &a, int grid = 0)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s g%d", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, S16 ? "st16" : "st8 ", grid);
+    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s mf%d g%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, S16 ? "st16" : "st8 ", MF, grid);
     const double nm = NQ - 1;
     b.run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ),
           a.out, a.nelmt * (size_t)NQ * NQ * NQ,
-          [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, S16>(a, 0, grid); });
+          [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, S16, MF>(a, 0, grid); });
 }
 
 template <int NQ, int EC, int WPB, int BM, int MW, int KM = 0, bool S16 = false>
@@ -133,24 +133,24 @@ int main(int argc, char **argv)
         HexArgs a{b0, b1, b2, in, nullptr, out, nelmt};
         if (nq == 8)
         {
-            hex_case<8, 2, 4, BASIS_SMEM, 4>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a);
-            hex_case<8, 2, 4, BASIS_LDS, 2, 0, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 1, true>(b, a);
             hex_case<8, 2, 4, BASIS_SMEM, 4, 2, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 4, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 8, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 16, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 64, true>(b, a);
-            hex_case<8, 2, 2, BASIS_SMEM, 4, 4, true>(b, a);
-            hex_case<8, 2, 1, BASIS_SMEM, 4, 4, true>(b, a);
-            hex_case<8, 2, 8, BASIS_SMEM, 4, 4, true>(b, a);
-            hex_case<8, 1, 4, BASIS_SMEM, 4, 8, false>(b, a);
-            hex_case<8, 4, 4, BASIS_SMEM, 2, 0, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 3, true>(b, a);
+            hex_case<8, 2, 8, BASIS_SMEM, 4, 2, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 1, true>(b, a);
             hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true>(b, a);
-            hex_case<8, 4, 4, BASIS_SMEM, 2, 4, true>(b, a);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a, 768);
-            hex_case<8, 2, 4, BASIS_SMEM, 4, 0, true>(b, a, 2560);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 3, true>(b, a);
+            hex_case<8, 4, 8, BASIS_SMEM, 2, 2, true>(b, a);
+            hex_case<8, 4, 2, BASIS_SMEM, 2, 2, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 3, 2, true>(b, a);
+            hex_case<8, 4, 4, BASIS_LDS, 2, 2, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true, 1>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true, 2>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true, 3>(b, a);
+            hex_case<8, 6, 4, BASIS_SMEM, 1, 1, true>(b, a);
+            hex_case<8, 6, 4, BASIS_SMEM, 1, 2, true>(b, a);
+            hex_case<8, 8, 4, BASIS_SMEM, 1, 1, true>(b, a);
+            hex_case<8, 4, 4, BASIS_SMEM, 2, 2, true>(b, a);
+            hex_case<8, 2, 4, BASIS_SMEM, 4, 2, true>(b, a);
         }
         else if (nq == 2) { hex_case<2, 64, 4, BASIS_LDS, 2>(b, a); hex_case<2, 64, 4, BASIS_SMEM, 2>(b, a); hex_case<2, 128, 4, BASIS_SMEM, 2>(b, a); }
         else if (nq == 3) { hex_case<3, 14, 4, BASIS_LDS, 2>(b, a); hex_case<3, 14, 4, BASIS_SMEM, 2>(b, a); hex_case<3, 28, 4, BASIS_SMEM, 2>(b, a); }

@@ -42,6 +42,16 @@ int oracle_max_threads(void)
 #endif
 }
 
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ---------------------------------------------------------------- initialisers ---------------- */
 
 /* in[e][f] = sin(f + 1), identical for every element (benchmark05.cc:1206-1207). */

@@ -36,6 +36,8 @@ def _lib(fast=False):
         lib = ctypes.CDLL(path)
         sz, u32, u64, dbl = ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint64, ctypes.c_double
         lib.oracle_max_threads.restype = ctypes.c_int
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.set_threads_done = False
         lib.oracle_fill_sincos.argtypes = [_c_dp, sz, sz]
         lib.oracle_fill_basis.argtypes = [_c_dp, sz, sz]
         lib.oracle_fill_random.argtypes = [_c_dp, sz, u64, u64]
@@ -61,8 +63,33 @@ def _p(a):
     return a.ctypes.data_as(_c_dp)
 
 
-def max_threads():
-    return int(_lib().oracle_max_threads())
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                tok = fh.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(int(tok[0]) / int(tok[1]))))
+            else:
+                quota = int(tok[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, quota // int(fh.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def set_threads(n, fast=False):
+    _lib(fast).oracle_set_threads(int(n))
+
+
+def max_threads(fast=False):
+    return int(_lib(fast).oracle_max_threads())
 
 
 # ---------------------------------------------------------------- initialisers -----------------
