@@ -76,14 +76,14 @@ def cpu_baseline(nq, seconds):
     """Oracle (-O3/AVX2/FMA build, OpenMP over elements) on a bounded sample of the same workload."""
     import oracle
     nm = nq - 1
-    sample = 131072
+    sample = 262144
     cores = oracle.usable_cpus()      # not omp_get_max_threads(): the box grants a CPU share
     for fast in (False, True):
         oracle.set_threads(cores, fast=fast)
     b = oracle.fill_basis(nm, nq)
     x = oracle.fill_random(sample * nm ** 3, 0x5F3759DF)
     best, spent, reps = float("inf"), 0.0, 0
-    while reps < 3 or (spent < seconds and reps < 40):
+    while reps < 3 or (spent < seconds and reps < 200):
         t0 = time.perf_counter()
         oracle.bwdtrans_hex((nq,) * 3, sample, b, b, b, x, form="sweeps", fast=True)
         dt = time.perf_counter() - t0
