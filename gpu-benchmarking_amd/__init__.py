@@ -12,7 +12,7 @@ Layout
 There is NO CPU fallback here: every compute entry point goes through libsumfact.so and raises if
 it is missing.
 """
-from . import capi, shard  # noqa: F401
+from . import capi, logfmt, shard  # noqa: F401
 from .bwdtrans import (  # noqa: F401
     bwdtrans_hex, bwdtrans_quad, sumsq, fill_sincos, fill_basis, fill_random, fill_l2norm,
     stream_copy, device_info, hex_wsp_doubles, quad_wsp_doubles, VARIANTS,

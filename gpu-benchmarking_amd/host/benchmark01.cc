@@ -1,0 +1,159 @@
+// benchmark01 -- L2 norm reduction driver.
+//
+// BASELINE config 0: the HOST path of benchmark01 (plumbing + outfile.log format parity, runs with
+// no GPU).  Keeps the reference driver's contract (benchmark01/benchmark01.cc:183, 337-348):
+//   ./benchmark01                     no arguments used
+//   run_test<T>(size) for size = 1024 .. 536 870 912 (doubling, 20 sizes)
+//   stdout: banner, then per size   Size N Case: ... / Size N norm: ... / Size N GB/s: ...
+//           (setprecision(10), single-space separators; GB/s = 8e-9*size/t_min, :330)
+// Columns:
+//   1 Host (OpenMP)   sum x^2 on the host cores (blocked pairwise summation: a serial fp64 running sum
+//                     drifts at 5e8 terms and would miss the published norms)
+//   2 HIP (vl)        sf_sumsq_f64 on the device (16-byte lanes, wave-64 shuffle tree); the timed region
+//                     includes the D2H copy of the scalar, as in the reference (:245-253).
+//                     Printed as 0 when no HIP device is visible.
+// data: x[i] = i%13 + (0.2 + 1e-5*(i%100191))  (:178).
+// Extra options: --max-size N, --json FILE.
+#include "harness.h"
+
+#include <omp.h>
+
+using namespace harness;
+
+static Options g_opt;
+static JsonLog g_json;
+static bool g_gpu = false;
+
+static void host_fill(double *x, size_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+    {
+        const unsigned int u = (unsigned int)i;
+        x[i]                 = u % 13u + (0.2 + 0.00001 * (u % 100191u));
+    }
+}
+
+// fixed 4096-term leaves, then a pairwise tree over the leaf sums: result independent of thread count
+static double host_sumsq(const double *x, size_t n)
+{
+    const size_t leaf   = 4096;
+    const size_t nleaf  = (n + leaf - 1) / leaf;
+    std::vector<double> part(nleaf);
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < (long long)nleaf; ++b)
+    {
+        const size_t lo = (size_t)b * leaf, hi = std::min(n, lo + leaf);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        size_t i = lo;
+        for (; i + 4 <= hi; i += 4)
+        {
+            s0 += x[i] * x[i];
+            s1 += x[i + 1] * x[i + 1];
+            s2 += x[i + 2] * x[i + 2];
+            s3 += x[i + 3] * x[i + 3];
+        }
+        for (; i < hi; ++i)
+            s0 += x[i] * x[i];
+        part[b] = (s0 + s1) + (s2 + s3);
+    }
+    size_t m = nleaf;
+    while (m > 1)
+    {
+        const size_t h = m / 2;
+#pragma omp parallel for schedule(static) if (h > 4096)
+        for (long long b = 0; b < (long long)h; ++b)
+            part[b] = part[2 * b] + part[2 * b + 1];
+        if (m & 1)
+        {
+            part[h] = part[m - 1];
+            m       = h + 1;
+        }
+        else
+            m = h;
+    }
+    return part[0];
+}
+
+template <typename T> void run_test(const unsigned int size)
+{
+    static_assert(sizeof(T) == sizeof(double), "only T = double is instantiated (as in the reference)");
+    Timer time;
+    const unsigned int n_tests = kTests;
+
+    // Host path
+    double time_host = std::numeric_limits<double>::max();
+    T result_host    = 0;
+    {
+        std::vector<T> data(size);
+        host_fill(data.data(), size);
+        double spent = 0.0;
+        for (unsigned int t = 0; t < n_tests; ++t)
+        {
+            time.start();
+            result_host = host_sumsq(data.data(), size);
+            time.stop();
+            time_host = std::min(time_host, time.elapsedSeconds());
+            spent += time.elapsedSeconds();
+            if (spent > 4.0 * kSlowBudgetS && t >= 2)
+                break;
+        }
+    }
+
+    // Device path
+    double time_hip = std::numeric_limits<double>::max();
+    T result_hip    = 0;
+    if (g_gpu)
+    {
+        DeviceBuffer<T> ddata(size);
+        SF_CHECK(sf_fill_l2norm_f64(ddata.get(), size, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        SF_CHECK(sf_sumsq_f64(ddata.get(), size, &result_hip, nullptr)); // warm-up
+        for (unsigned int t = 0; t < n_tests; ++t)
+        {
+            time.start();
+            SF_CHECK(sf_sumsq_f64(ddata.get(), size, &result_hip, nullptr)); // includes D2H + sync
+            time.stop();
+            time_hip = std::min(time_hip, time.elapsedSeconds());
+        }
+    }
+
+    // Display results (grammar of benchmark01.cc:317-334)
+    std::cout << std::setprecision(10);
+    std::cout << "Size " << size << " Case:     Host (OpenMP)      HIP (vl)" << std::endl;
+    std::cout << "Size " << size << " norm: " << std::sqrt(result_host) << " " << std::sqrt(result_hip)
+              << std::endl;
+    std::cout << "Size " << size << " GB/s: " << sizeof(T) * 1e-9 * size / time_host << " "
+              << (g_gpu ? sizeof(T) * 1e-9 * size / time_hip : 0.0) << std::endl;
+
+    std::ostringstream r;
+    r << std::setprecision(10) << "{\"size\": " << size << ", \"host_gb_s\": "
+      << sizeof(T) * 1e-9 * size / time_host << ", \"hip_gb_s\": "
+      << (g_gpu ? sizeof(T) * 1e-9 * size / time_hip : 0.0) << ", \"norm_host\": "
+      << std::sqrt(result_host) << ", \"norm_hip\": " << std::sqrt(result_hip) << "}";
+    g_json.row(r.str());
+}
+
+int main(int argc, char **argv)
+{
+    g_opt = parse(argc, argv);
+    g_gpu = have_gpu();
+    std::cout << "--------------------------------" << std::endl;
+    std::cout << "Benchmark01 : L2 norm reduction " << std::endl;
+    std::cout << "--------------------------------" << std::endl;
+    if (!g_gpu)
+        std::cerr << "benchmark01: no HIP device visible, host column only (device column printed as 0)"
+                  << std::endl;
+    for (unsigned int size = 1024; size < 1000000000u; size *= 2)
+    {
+        if (g_opt.maxsize > 0 && size > g_opt.maxsize)
+            break;
+        run_test<double>(size);
+    }
+    std::ostringstream h;
+    h << device_header() << ", \"benchmark\": \"benchmark01\", \"host_threads\": " << omp_get_max_threads();
+    g_json.write(g_opt.json, h.str());
+    if (g_gpu)
+        (void)sf_shutdown();
+    return 0;
+}

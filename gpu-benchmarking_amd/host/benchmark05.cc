@@ -1,0 +1,138 @@
+// benchmark05 -- BwdTrans (3D hex) driver for MI355X.
+//
+// Keeps the reference driver's contract (benchmark05/benchmark05.cc:619-622, 1423-1442):
+//   ./benchmark05 [nq0 nq1 nq2 threads elblocks]     defaults 8 8 8 128 1
+//   run_test<T>(size, nq0, nq1, nq2, threads, elblocks) for size = 128 .. 1 048 576 (doubling)
+//   stdout: banner, "BwdTrans (NQ = a, b, c)", then per size the three lines
+//           nelmt N Case: ... / nelmt N norm: ... / nelmt N DOF/s: ...   (setprecision(10), 5 spaces)
+// so the reference's postprocess.py parses the log unchanged.  The columns are this build's kernels,
+// all behind the C ABI of libsumfact.so:
+//   1 HIP (thread/elmt)     one thread per element, fused nest        (decomposition of :15-102)
+//   2 HIP (block/elmt glb)  one workgroup per element, global wsp     (:431-508)
+//   3 HIP (block/elmt LDS)  one workgroup per element, all in LDS     (:510-617)
+//   4 HIP (wave/chunk)      flagship: one wavefront streams chunks    (sf_bwdtrans_hex_f64)
+// `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
+// Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
+// --no-baselines, --seed S.
+#include "harness.h"
+
+using namespace harness;
+
+static Options g_opt;
+static JsonLog g_json;
+
+template <typename T>
+void run_test(const unsigned int size, const unsigned int _nq0, const unsigned int _nq1,
+              const unsigned int _nq2, const unsigned int _threads, const unsigned int _elblocks)
+{
+    static_assert(sizeof(T) == sizeof(double), "only T = double is instantiated (as in the reference)");
+    (void)_threads;
+    (void)_elblocks;
+    const size_t nelmt = size;
+    const unsigned nq0 = _nq0, nq1 = _nq1, nq2 = _nq2;
+    const unsigned nm0 = nq0 - 1u, nm1 = nq1 - 1u, nm2 = nq2 - 1u;
+    const size_t nmTot = (size_t)nm0 * nm1 * nm2, nqTot = (size_t)nq0 * nq1 * nq2;
+
+    DeviceBuffer<T> d_in(nelmt * nmTot), d_out(nelmt * nqTot);
+    DeviceBuffer<T> d_basis0(nm0 * nq0), d_basis1(nm1 * nq1), d_basis2(nm2 * nq2);
+    DeviceBuffer<T> d_wsp(g_opt.baselines ? nelmt * ((size_t)nq0 * nm1 * nm2 + (size_t)nq0 * nq1 * nm2) : 0);
+
+    // in[e][f] = sin(f+1), basis[x] = cos(x)  (benchmark05.cc:1195-1236), generated on the device
+    if (g_opt.data == "random")
+        SF_CHECK(sf_fill_random_f64(d_in.get(), nelmt * nmTot, g_opt.seed, 0, nullptr));
+    else
+        SF_CHECK(sf_fill_sincos_f64(d_in.get(), nelmt, nmTot, nullptr));
+    SF_CHECK(sf_fill_basis_f64(d_basis0.get(), nm0, nq0, nullptr));
+    SF_CHECK(sf_fill_basis_f64(d_basis1.get(), nm1, nq1, nullptr));
+    SF_CHECK(sf_fill_basis_f64(d_basis2.get(), nm2, nq2, nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+
+    const int variants[4]  = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
+                              SF_VARIANT_AUTO};
+    const char *names[4]   = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                              "HIP (wave/chunk)"};
+    double times[4], results[4];
+    for (int v = 0; v < 4; ++v)
+    {
+        times[v]   = std::numeric_limits<double>::max();
+        results[v] = 0.0;
+        if (!g_opt.baselines && v != 3)
+            continue;
+        HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
+        auto launch = [&]()
+        {
+            SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt, d_basis0.get(),
+                                                 d_basis1.get(), d_basis2.get(), d_in.get(),
+                                                 d_wsp.get(), d_out.get(), nullptr));
+        };
+        launch(); // first touch outside the timed loop
+        HIP_CHECK(hipDeviceSynchronize());
+        times[v] = time_min(launch, v == 3 ? 1e30 : kSlowBudgetS);
+        SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
+    }
+
+    // Display results (grammar of benchmark05.cc:1387-1420)
+    std::cout << std::setprecision(10);
+    std::cout << "nelmt " << nelmt << " Case:";
+    for (int v = 0; v < 4; ++v)
+        std::cout << " " << names[v];
+    std::cout << std::endl;
+    std::cout << "nelmt " << nelmt << " norm: ";
+    for (int v = 0; v < 4; ++v)
+        std::cout << (v ? "     " : "") << std::sqrt(results[v]);
+    std::cout << std::endl;
+    std::cout << "nelmt " << nelmt << " DOF/s: ";
+    for (int v = 0; v < 4; ++v)
+    {
+        const double dofs = times[v] < 1e300 ? 1.0e-9 * nelmt * (double)nmTot / times[v] : 0.0;
+        std::cout << (v ? "     " : "") << dofs;
+    }
+    std::cout << std::endl;
+    std::cout << std::flush;
+
+    const double bytes = 8.0 * nelmt * (double)(nmTot + nqTot);
+    std::ostringstream r;
+    r << std::setprecision(10) << "{\"nelmt\": " << nelmt << ", \"nq\": [" << nq0 << "," << nq1 << ","
+      << nq2 << "], \"wave_gdof_s\": " << 1.0e-9 * nelmt * (double)nmTot / times[3]
+      << ", \"wave_gb_s\": " << 1.0e-9 * bytes / times[3]
+      << ", \"wave_frac_hbm_roofline\": " << 1.0e-9 * bytes / times[3] / kHbmPeakGBs
+      << ", \"norm\": " << std::sqrt(results[3]) << "}";
+    g_json.row(r.str());
+}
+
+int main(int argc, char **argv)
+{
+    g_opt                 = parse(argc, argv);
+    unsigned int nq0      = positional(g_opt, 0, 8u);
+    unsigned int nq1      = positional(g_opt, 1, 8u);
+    unsigned int nq2      = positional(g_opt, 2, 8u);
+    unsigned int threads  = positional(g_opt, 3, 128u);
+    unsigned int elblocks = positional(g_opt, 4, 1u);
+
+    std::cout << "--------------------------------" << std::endl;
+    std::cout << "Benchmark05 : BwdTrans (3D)     " << std::endl;
+    std::cout << "--------------------------------" << std::endl;
+    std::cout << "BwdTrans (NQ = " << nq0 << ", " << nq1 << ", " << nq2 << ")" << std::endl;
+    if (nq0 < 2 || nq1 < 2 || nq2 < 2)
+    {
+        std::cerr << "nq must be >= 2 in every direction" << std::endl;
+        return 1;
+    }
+    if (!have_gpu())
+    {
+        std::cerr << "benchmark05: no HIP device visible; the kernels have no CPU fallback" << std::endl;
+        return 4;
+    }
+    if (g_opt.nelmt > 0)
+        run_test<double>((unsigned)g_opt.nelmt, nq0, nq1, nq2, threads, elblocks);
+    else
+        for (unsigned int size = 2 << 6; size < 2 << 20; size <<= 1)
+        {
+            if (g_opt.maxsize > 0 && size > g_opt.maxsize)
+                break;
+            run_test<double>(size, nq0, nq1, nq2, threads, elblocks);
+        }
+    g_json.write(g_opt.json, device_header() + ", \"benchmark\": \"benchmark05\"");
+    (void)sf_shutdown();
+    return 0;
+}

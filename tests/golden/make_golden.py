@@ -52,10 +52,18 @@ def main():
                                 "rows": parse(path, "nelmt", 8)}
     path = f"{REF}/benchmark01/outfile.log"
     out["l2norm"] = {"file": os.path.relpath(path, REF), "rows": parse(path, "Size", 1)}
+    # grammar fixtures: the first lines (banner + two sizes) of one log per benchmark, verbatim
+    # result data of the reference, used by tests/test_logfmt.py to pin the log grammar
+    out["log_excerpts"] = {}
+    for rel, nlines in (("benchmark05/nq8x8x8.log", 10), ("benchmark04/nq8x8.log", 10),
+                        ("benchmark01/outfile.log", 9)):
+        with open(f"{REF}/{rel}") as fh:
+            out["log_excerpts"][rel] = "".join(fh.readlines()[:nlines])
     with open(OUT, "w") as fh:
         json.dump(out, fh, indent=1)
     n = sum(len(v["rows"]) for v in out["hex"].values()) + \
         sum(len(v["rows"]) for v in out["quad"].values()) + len(out["l2norm"]["rows"])
+    assert n == 216
     print(f"wrote {OUT}: {n} known-answer values")
 
 

@@ -1,0 +1,88 @@
+"""GPU: the C++ drivers (reference CLI + log grammar) run on the device, their logs parse under the
+reference's postprocess grammar, and their `norm:` columns reproduce the published values."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "gpu-benchmarking_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.load_package()
+
+
+def _run(args, timeout=900):
+    res = subprocess.run(args, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return res.stdout
+
+
+def test_benchmark05_default_cli_sweep(pkg, golden, tmp_path):
+    js = tmp_path / "b5.json"
+    out = _run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "--max-size", "16384",
+                "--json", str(js)])
+    lines = out.splitlines()
+    assert lines[:4] == ["-" * 32, "Benchmark05 : BwdTrans (3D)     ", "-" * 32,
+                         "BwdTrans (NQ = 8, 8, 8)"]
+    log = pkg.logfmt.parse_log(out)
+    assert log.kind == "DOF/s" and log.ncols == 4 and log.title == "BwdTrans (NQ = 8, 8, 8)"
+    assert log.sizes == [float(128 << k) for k in range(8)]
+    want = {r["n"]: float(r["norm"]) for r in golden["hex"]["8"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        for v in norms:                       # every variant reproduces the published norm
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
+    rec = json.loads(js.read_text())
+    assert rec["benchmark"] == "benchmark05" and len(rec["rows"]) == 8
+
+
+def test_benchmark05_headline_size(pkg, golden):
+    out = _run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "128", "1", "--nelmt", "1048576",
+                "--no-baselines"])
+    log = pkg.logfmt.parse_log(out)
+    assert log.sizes == [1048576.0]
+    assert abs(log.norms[0][3] - 17134.76235) <= 5.5e-10 * 17134.76235
+    assert log.values[0][3] > 100.0           # GDOF/s of the flagship column (reference best: 26.4)
+
+
+def test_benchmark04_default_cli_sweep(pkg, golden):
+    out = _run([os.path.join(BIN, "benchmark04"), "8", "8", "--max-size", "16384"])
+    lines = out.splitlines()
+    assert lines[1] == "Benchmark04 : BwdTrans (2D)     " and lines[3] == "BwdTrans (NQ = 8, 8)"
+    log = pkg.logfmt.parse_log(out)
+    assert log.ncols == 4
+    want = {r["n"]: float(r["norm"]) for r in golden["quad"]["8"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        for v in norms:
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
+
+
+def test_benchmark01_device_column(pkg, golden):
+    out = _run([os.path.join(BIN, "benchmark01"), "--max-size", str(1 << 24)])
+    log = pkg.logfmt.parse_log(out)
+    assert log.ncols == 2
+    want = {r["n"]: float(r["norm"]) for r in golden["l2norm"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        for v in norms:                       # host and device columns
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)]
+
+
+def test_anisotropic_cli(pkg, oracle):
+    """nq0 != nq1 != nq2 takes the generic path; norm checked against the oracle."""
+    import math
+    out = _run([os.path.join(BIN, "benchmark05"), "3", "5", "4", "--nelmt", "1000"])
+    log = pkg.logfmt.parse_log(out)
+    b = [oracle.fill_basis(q - 1, q) for q in (3, 5, 4)]
+    ref = oracle.bwdtrans_hex((3, 5, 4), 1000, *b, oracle.fill_sincos(1000, 2 * 4 * 3))
+    norm = math.sqrt(oracle.sumsq(ref))
+    for v in log.norms[0]:
+        assert abs(v - norm) <= 1e-9 * norm

@@ -1,0 +1,78 @@
+"""Log-grammar contract: our drivers' logs must parse under the grammar the reference's postprocess.py
+defines (line filters, split()[1], split()[3:], equal column counts, <= 11 / <= 5 columns), and the
+reference's own logs must parse with the same code.  The excerpts under tests/golden are result data
+of the reference (first lines of three committed logs)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "gpu-benchmarking_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(BIN, "benchmark01")):
+        ge.build()
+    return ge.load_package()
+
+
+def test_reference_excerpts_parse(pkg, golden):
+    ex = golden["log_excerpts"]
+    hexlog = pkg.logfmt.parse_log(ex["benchmark05/nq8x8x8.log"])
+    assert hexlog.kind == "DOF/s" and hexlog.ncols == 11
+    assert hexlog.title == "BwdTrans (NQ = 8, 8, 8)"
+    assert hexlog.sizes == [128.0, 256.0]
+    assert abs(hexlog.norms[0][8] - 189.3141665) < 1e-9
+    quad = pkg.logfmt.parse_log(ex["benchmark04/nq8x8.log"])
+    assert quad.ncols == 11 and quad.title == "BwdTrans (NQ = 8, 8)"
+    l2 = pkg.logfmt.parse_log(ex["benchmark01/outfile.log"])
+    assert l2.kind == "GB/s" and l2.ncols == 5 and l2.sizes == [1024.0, 2048.0]
+    assert abs(l2.norms[0][0] - 231.3925755) < 1e-9
+
+
+def test_grammar_violations_rejected(pkg):
+    with pytest.raises(ValueError):
+        pkg.logfmt.parse_log("nothing here\n")
+    bad = "nelmt 128 DOF/s: 1 2 3\nnelmt 256 DOF/s: 1 2\n"
+    with pytest.raises(ValueError):
+        pkg.logfmt.parse_log(bad)
+    wide = "nelmt 128 DOF/s: " + " ".join(["1"] * 12) + "\n"
+    with pytest.raises(ValueError):
+        pkg.logfmt.parse_log(wide)
+
+
+def test_benchmark01_host_path_log(pkg, golden, tmp_path):
+    """BASELINE config 0: benchmark01 host path, no GPU needed: banner, grammar, published norms."""
+    exe = os.path.join(BIN, "benchmark01")
+    js = tmp_path / "bm01.json"
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    res = subprocess.run([exe, "--max-size", str(1 << 21), "--json", str(js)], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr
+    out = res.stdout
+    lines = out.splitlines()
+    assert lines[0] == "-" * 32 and lines[1] == "Benchmark01 : L2 norm reduction " and lines[2] == "-" * 32
+    log = pkg.logfmt.parse_log(out)
+    assert log.kind == "GB/s" and log.ncols == 2 and len(log.sizes) == 12
+    assert log.sizes[0] == 1024.0 and log.sizes[-1] == float(1 << 21)
+    # three lines per size
+    assert len(lines) == 3 + 3 * len(log.sizes)
+    want = {row["n"]: float(row["norm"]) for row in golden["l2norm"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        assert abs(norms[0] - want[int(size)]) <= 5.5e-10 * want[int(size)]
+    assert js.exists() and '"benchmark": "benchmark01"' in js.read_text()
+
+
+def test_postprocess_plots(pkg, golden, tmp_path):
+    pytest.importorskip("matplotlib")
+    import importlib
+    pp = importlib.import_module("gpu_benchmarking_amd.postprocess")
+    path = tmp_path / "nq8x8x8.log"
+    path.write_text(golden["log_excerpts"]["benchmark05/nq8x8x8.log"])
+    png = pp.plot(str(path), roofline=True)
+    assert png.endswith("nq8x8x8.png") and os.path.getsize(png) > 1000
+    assert abs(pp.roofline_gdofs("BwdTrans (NQ = 8, 8, 8)") - 401.17) < 0.01
+    assert abs(pp.roofline_gdofs("BwdTrans (NQ = 8, 8)") - 433.63) < 0.01
