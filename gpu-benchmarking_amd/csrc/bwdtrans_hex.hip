@@ -9,28 +9,28 @@ namespace sf
 // NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
 // (0 = persistent), 16-byte stores
 template <int NQ> struct HexCfg;
-#define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, S16_)                                            \
+#define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_)                                            \
     template <> struct HexCfg<NQ_>                                                                 \
     {                                                                                              \
         static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_;                   \
-        static constexpr bool S16 = S16_;                                                          \
+        static constexpr int OUT = OUT_;                                                           \
     }
-//          nq  EC  WPB  basis       MINW KMAP st16
-SF_HEX_CFG(2,  64, 4, BASIS_SMEM, 2, 2, true);
-SF_HEX_CFG(3,  14, 4, BASIS_SMEM, 2, 2, false);
-SF_HEX_CFG(4,  8,  4, BASIS_SMEM, 2, 2, true);
-SF_HEX_CFG(5,  5,  4, BASIS_SMEM, 2, 2, false);
-SF_HEX_CFG(6,  6,  4, BASIS_SMEM, 2, 2, true);
-SF_HEX_CFG(7,  5,  4, BASIS_SMEM, 2, 2, false);
-SF_HEX_CFG(8,  4,  4, BASIS_SMEM, 2, 2, true); // 302 GDOF/s min / 287 mean @1Mi (tune8c.log)
-SF_HEX_CFG(9,  2,  4, BASIS_SMEM, 2, 2, false);
-SF_HEX_CFG(10, 2,  4, BASIS_SMEM, 2, 2, true);
+//          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
+SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16); //  73 /  70
+SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 166 / 162
+SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 227 / 223
+SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 247 / 243
+SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 278 / 272
+SF_HEX_CFG(7,  4,   4, BASIS_SMEM, 1, 2, OUT_LDS);  // 268 / 265
+SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16); // 295-302 / 287
+SF_HEX_CFG(9,  2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 277 / 274
+SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 310 / 306
 #undef SF_HEX_CFG
 
 template <int NQ> static int go(const HexArgs &a, hipStream_t s)
 {
     using C = HexCfg<NQ>;
-    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16>(a, s);
+    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 
 // returns SF_ENOTBUILT when nq has no instantiation

@@ -5,23 +5,36 @@
 namespace sf
 {
 
-template <int NQ> struct QuadCfg
-{
-    // default: fill one wave pass with elements, two passes per lane
-    static constexpr int PER = (kWave / NQ) < 1 ? 1 : (kWave / NQ);
-    static constexpr int EC0 = (NQ <= 10) ? 2 * PER : PER;
-    // chunk must hold an even number of doubles for the 16-byte loads
-    static constexpr int EC  = ((EC0 * (NQ - 1) * (NQ - 1)) % 2 == 0) ? EC0 : EC0 + 1;
-    // scalar-operand rows need 2*NQ SGPRs each (ring of 3): beyond nq ~ 10 they spill -> LDS copy
-    static constexpr int WPB = 4, BM = (NQ <= 10) ? BASIS_SMEM : BASIS_LDS, MW = (NQ <= 16) ? 2 : 1,
-                         KM = 2;
-    static constexpr bool S16 = (NQ % 2 == 0);
-};
+template <int NQ> struct QuadCfg;
+#define SF_QUAD_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_)                                           \
+    template <> struct QuadCfg<NQ_>                                                                \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_, OUT = OUT_;       \
+    }
+// scalar-operand rows need 2*nq SGPRs each (ring of 3): beyond nq ~ 10 they spill -> LDS copy of the basis
+//           nq  EC  WPB  basis      MINW KMAP out        GDOF/s min/mean @1Mi (profiles/r01/tune_quad*.log)
+SF_QUAD_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_LDS);  // 115 / 112 (9 us kernel: launch-bound)
+SF_QUAD_CFG(3,  42,  4, BASIS_SMEM, 2, 1, OUT_LDS);
+SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 265 / 251
+SF_QUAD_CFG(5,  24,  4, BASIS_SMEM, 2, 1, OUT_LDS);
+SF_QUAD_CFG(6,  10,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 311 / 304
+SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS);
+SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16); // 336 / 331
+SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS);
+SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS);  // 336 / 329
+SF_QUAD_CFG(11, 10,  4, BASIS_LDS,  1, 1, OUT_LDS);
+SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS);  // 339 / 331
+SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);
+SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);  // 322 / 295
+SF_QUAD_CFG(15, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);
+SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16); // 325 / 302
+SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16); // 118 / 117: VALU-issue-bound (MFMA path: next)
+#undef SF_QUAD_CFG
 
 template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
 {
     using C = QuadCfg<NQ>;
-    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::S16>(a, s);
+    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

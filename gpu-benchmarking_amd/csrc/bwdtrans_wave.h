@@ -35,6 +35,14 @@
 namespace sf
 {
 
+// How the last sweep's results reach HBM.
+enum OutMode
+{
+    OUT_ST8  = 0, // straight from registers, 8 B per lane (any nq)
+    OUT_ST16 = 1, // straight from registers, lane pairs swap through DPP -> 16 B per lane (even nq)
+    OUT_LDS  = 2  // through the LDS slab in final layout, then one flat 16-B-per-lane stream (any nq)
+};
+
 // How the wave-uniform basis operand is delivered to the FMAs.
 enum BasisMode
 {
@@ -73,15 +81,24 @@ template <int NQ, int EC, int DIM> struct WaveGeom
     static constexpr int SLAB_W1 = P1 * NMP;
     static constexpr int SLAB_W2 = (DIM == 3) ? P2 * NMP : 0;
     static constexpr int SLAB0   = CMax<CMax<SLAB_IN, SLAB_W1>::value, SLAB_W2>::value;
-    static constexpr int SLAB    = (SLAB0 + 1) & ~1; // keep slabs 16-B aligned
+    static constexpr int OUT_DBL = EC * NQT;          // doubles per chunk written to HBM
+    // slab without / with room for the output image (OUT_LDS), kept 16-B aligned
+    static constexpr int SLAB_NOOUT = (SLAB0 + 1) & ~1;
+    static constexpr int SLAB_OUT   = (CMax<SLAB0, OUT_DBL>::value + 1) & ~1;
     static constexpr int NBAS    = (NM * NQ + 1) & ~1;
     static constexpr int NLD     = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
 };
 
-template <int NQ, int EC, int DIM, int WPB, int BMODE> constexpr size_t wave_lds_bytes()
+template <class G, int OUTM> constexpr int slab_doubles()
+{
+    return OUTM == 2 ? G::SLAB_OUT : G::SLAB_NOOUT;
+}
+
+template <int NQ, int EC, int DIM, int WPB, int BMODE, int OUTM> constexpr size_t wave_lds_bytes()
 {
     using G = WaveGeom<NQ, EC, DIM>;
-    return sizeof(double) * (size_t)((BMODE == BASIS_LDS ? DIM * G::NBAS : 0) + WPB * G::SLAB);
+    return sizeof(double) *
+           (size_t)((BMODE == BASIS_LDS ? DIM * G::NBAS : 0) + WPB * slab_doubles<G, OUTM>());
 }
 
 // chunk iteration space of one wave
@@ -272,7 +289,7 @@ __device__ __forceinline__ void read_pencils(double (&u)[NPASS][NIN], const doub
 // ------------------------------------------------------------------------------------------------
 // shared prologue: basis pointers (LDS copy or the global arrays themselves) and the wave's slab
 // ------------------------------------------------------------------------------------------------
-template <class G, int DIM, int WPB, int BMODE>
+template <class G, int DIM, int WPB, int BMODE, int SLAB>
 __device__ __forceinline__ double *wave_setup(double *lds, const double *const (&gb)[3],
                                               const double *(&bs)[3], int wib)
 {
@@ -286,14 +303,14 @@ __device__ __forceinline__ double *wave_setup(double *lds, const double *const (
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
             bs[d] = lds + d * G::NBAS;
-        return lds + DIM * G::NBAS + wib * G::SLAB;
+        return lds + DIM * G::NBAS + wib * SLAB;
     }
     else
     {
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
             bs[d] = gb[d];
-        return lds + wib * G::SLAB;
+        return lds + wib * SLAB;
     }
 }
 
@@ -345,24 +362,69 @@ __device__ __forceinline__ void store_column(const double (&acc)[NOUT], double *
     }
 }
 
+// OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` doubles to HBM
+// with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is even; else 8-B lanes).
+template <class G, bool NTS>
+__device__ __forceinline__ void chunk_flush(const double *slab, double *__restrict__ dst, int nout,
+                                            int lane)
+{
+    if constexpr (G::OUT_DBL % 2 == 0)
+    {
+        constexpr int NST = cdiv(G::OUT_DBL / 2, kWave);
+        double2_t *dst2   = reinterpret_cast<double2_t *>(dst);
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+        {
+            const int v = k * kWave + lane;
+            if (2 * v + 1 < nout)
+            {
+                const double2_t x = *reinterpret_cast<const double2_t *>(slab + 2 * v);
+                if (NTS)
+                    __builtin_nontemporal_store(x, dst2 + v);
+                else
+                    dst2[v] = x;
+            }
+            else if (2 * v < nout)
+                dst[2 * v] = slab[2 * v];
+        }
+    }
+    else
+    {
+        constexpr int NST = cdiv(G::OUT_DBL, kWave);
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+        {
+            const int v = k * kWave + lane;
+            if (v < nout)
+            {
+                if (NTS)
+                    __builtin_nontemporal_store(slab[v], dst + v);
+                else
+                    dst[v] = slab[v];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3D hex
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
     const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
 {
     using G          = WaveGeom<NQ, EC, 3>;
     constexpr int NM = G::NM, NMP = G::NMP, NM2 = NM * NM, NQ2 = NQ * NQ;
-    static_assert(!ST16 || (NQ % 2 == 0), "16-byte stores need even nq");
+    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0), "paired 16-byte stores need even nq");
+    constexpr int SLAB = slab_doubles<G, OUTM>();
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *const gb[3] = {b0, b1, b2};
     const double *bs[3];
-    double *slab = wave_setup<G, 3, WPB, BMODE>(lds, gb, bs, wib);
+    double *slab = wave_setup<G, 3, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
@@ -435,13 +497,36 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
             read_pencils<NM, G::PASS2, G::P2, NMP>(u, slab, lane);
             contract<NM, NQ, G::PASS2, BMODE>(u, acc, bs[2]);
             double *oc = out + c * (uint64_t)(EC * G::NQT);
-#pragma unroll
-            for (int s = 0; s < G::PASS2; ++s)
+            if constexpr (OUTM == OUT_LDS)
             {
-                const int t = s * kWave + lane;
-                const int e = t / NQ2, pl = t - e * NQ2;
-                if (((s + 1) * kWave <= G::P2 || t < G::P2) && e < evalid)
-                    store_column<NQ, NQ2, ST16, !(MEMF & 2)>(acc[s], oc + e * G::NQT + pl, lane);
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < G::PASS2; ++s)
+                {
+                    const int t = s * kWave + lane;
+                    if ((s + 1) * kWave <= G::P2 || t < G::P2)
+                    {
+                        const int e = t / NQ2, pl = t - e * NQ2;
+                        double *dst = slab + e * G::NQT + pl;
+#pragma unroll
+                        for (int k = 0; k < NQ; ++k)
+                            dst[k * NQ2] = acc[s][k];
+                    }
+                }
+                wave_lds_fence();
+                chunk_flush<G, !(MEMF & 2)>(slab, oc, evalid * G::NQT, lane);
+            }
+            else
+            {
+#pragma unroll
+                for (int s = 0; s < G::PASS2; ++s)
+                {
+                    const int t = s * kWave + lane;
+                    const int e = t / NQ2, pl = t - e * NQ2;
+                    if (((s + 1) * kWave <= G::P2 || t < G::P2) && e < evalid)
+                        store_column<NQ, NQ2, OUTM == OUT_ST16, !(MEMF & 2)>(
+                            acc[s], oc + e * G::NQT + pl, lane);
+                }
             }
             wave_lds_fence(); // slab is rewritten by the next chunk's staging
         }
@@ -451,21 +536,22 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
 // ------------------------------------------------------------------------------------------------
 // 2D quad
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, bool ST16, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
 {
     using G          = WaveGeom<NQ, EC, 2>;
     constexpr int NM = G::NM, NMP = G::NMP;
-    static_assert(!ST16 || (NQ % 2 == 0), "16-byte stores need even nq");
+    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0), "paired 16-byte stores need even nq");
+    constexpr int SLAB = slab_doubles<G, OUTM>();
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *const gb[3] = {b0, b1, nullptr};
     const double *bs[3];
-    double *slab = wave_setup<G, 2, WPB, BMODE>(lds, gb, bs, wib);
+    double *slab = wave_setup<G, 2, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
@@ -513,13 +599,36 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
             read_pencils<NM, G::PASS1, G::P1, NMP>(u, slab, lane);
             contract<NM, NQ, G::PASS1, BMODE>(u, acc, bs[1]);
             double *oc = out + c * (uint64_t)(EC * G::NQT);
-#pragma unroll
-            for (int s = 0; s < G::PASS1; ++s)
+            if constexpr (OUTM == OUT_LDS)
             {
-                const int t = s * kWave + lane;
-                const int e = t / NQ, i = t - e * NQ;
-                if (((s + 1) * kWave <= G::P1 || t < G::P1) && e < evalid)
-                    store_column<NQ, NQ, ST16, !(MEMF & 2)>(acc[s], oc + e * G::NQT + i, lane);
+                wave_lds_fence();
+#pragma unroll
+                for (int s = 0; s < G::PASS1; ++s)
+                {
+                    const int t = s * kWave + lane;
+                    if ((s + 1) * kWave <= G::P1 || t < G::P1)
+                    {
+                        const int e = t / NQ, i = t - e * NQ;
+                        double *dst = slab + e * G::NQT + i;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j)
+                            dst[j * NQ] = acc[s][j];
+                    }
+                }
+                wave_lds_fence();
+                chunk_flush<G, !(MEMF & 2)>(slab, oc, evalid * G::NQT, lane);
+            }
+            else
+            {
+#pragma unroll
+                for (int s = 0; s < G::PASS1; ++s)
+                {
+                    const int t = s * kWave + lane;
+                    const int e = t / NQ, i = t - e * NQ;
+                    if (((s + 1) * kWave <= G::P1 || t < G::P1) && e < evalid)
+                        store_column<NQ, NQ, OUTM == OUT_ST16, !(MEMF & 2)>(
+                            acc[s], oc + e * G::NQT + i, lane);
+                }
             }
             wave_lds_fence();
         }

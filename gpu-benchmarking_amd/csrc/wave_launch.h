@@ -33,12 +33,12 @@ template <class K> inline int resident_blocks(K kern, int threads, size_t lds, i
     return cache[dev] * device_info().num_cu;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, bool ST16 = false, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0>
 inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, ST16, MEMF>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE>();
+    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE, OUTM>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;
@@ -57,12 +57,12 @@ inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, bool ST16 = false, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0>
 inline int launch_quad_wave(const QuadArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, ST16, MEMF>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE>();
+    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE, OUTM>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;
