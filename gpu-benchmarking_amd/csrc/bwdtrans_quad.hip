@@ -37,6 +37,32 @@ template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 
+// matrix-core kernel (bwdtrans_mfma.h): every order 11..32; chunks of 2 elements
+template <int NQ> static int go_mfma(const QuadArgs &a, hipStream_t s)
+{
+    return launch_quad_mfma<NQ, 2, 4, 1, (NQ <= 16 ? 1 : 2)>(a, s);
+}
+
+int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
+{
+    switch (nq)
+    {
+#define SF_CASE(N) case N: return go_mfma<N>(a, s);
+        SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16) SF_CASE(17)
+        SF_CASE(18) SF_CASE(19) SF_CASE(20) SF_CASE(21) SF_CASE(22) SF_CASE(23) SF_CASE(24)
+        SF_CASE(25) SF_CASE(26) SF_CASE(27) SF_CASE(28) SF_CASE(29) SF_CASE(30) SF_CASE(31)
+        SF_CASE(32)
+#undef SF_CASE
+    default: return SF_ENOTBUILT;
+    }
+}
+
+// order at and above which SF_VARIANT_AUTO prefers the matrix-core kernel
+unsigned quad_mfma_threshold()
+{
+    return 13;
+}
+
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
 {
     switch (nq)

@@ -10,6 +10,8 @@ namespace sf
 {
 int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
+int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
+unsigned quad_mfma_threshold();
 int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
                        hipStream_t s);
 int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);
@@ -135,7 +137,12 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
     {
         if (iso && vec_ok)
         {
-            int rc = launch_quad_wave_nq(nq0, a, s);
+            // high order is compute-bound on the vector ALUs: matrix cores first
+            int rc = nq0 >= quad_mfma_threshold() ? launch_quad_mfma_nq(nq0, a, s) : SF_ENOTBUILT;
+            if (rc == SF_ENOTBUILT)
+                rc = launch_quad_wave_nq(nq0, a, s);
+            if (rc == SF_ENOTBUILT)
+                rc = launch_quad_mfma_nq(nq0, a, s);
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
@@ -147,6 +154,12 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
         if (!vec_ok)
             return SF_EALIGN;
         return launch_quad_wave_nq(nq0, a, s);
+    case SF_VARIANT_MFMA:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_quad_mfma_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
         return launch_quad_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
     case SF_VARIANT_THREAD:

@@ -11,7 +11,7 @@
 //   3 HIP (block/elmt LDS)  BwdTransQuadKernel_QP_1D, shared           (:353-426)
 //   4 HIP (wave/chunk)      flagship (sf_bwdtrans_quad_f64)
 // Extra options AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
-// --no-baselines, --seed S.
+// --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4).
 #include "harness.h"
 
 using namespace harness;
@@ -45,7 +45,7 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     HIP_CHECK(hipDeviceSynchronize());
 
     const int variants[4] = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
-                             SF_VARIANT_AUTO};
+                             g_opt.variant};
     const char *names[4]  = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
                              "HIP (wave/chunk)"};
     double times[4], results[4];

@@ -13,7 +13,7 @@
 //   4 HIP (wave/chunk)      flagship: one wavefront streams chunks    (sf_bwdtrans_hex_f64)
 // `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
-// --no-baselines, --seed S.
+// --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4).
 #include "harness.h"
 
 using namespace harness;
@@ -48,7 +48,7 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     HIP_CHECK(hipDeviceSynchronize());
 
     const int variants[4]  = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
-                              SF_VARIANT_AUTO};
+                              g_opt.variant};
     const char *names[4]   = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
                               "HIP (wave/chunk)"};
     double times[4], results[4];

@@ -110,6 +110,7 @@ struct Options
     std::string data  = "sincos"; // --data sincos|random
     std::string json;            // --json FILE
     bool baselines    = true;    // --no-baselines : only the flagship column is timed
+    int variant       = SF_VARIANT_AUTO; // --variant auto|wave|mfma|... : kernel of the flagship column
     unsigned seed     = 0x5F3759DFu;
 };
 
@@ -140,6 +141,19 @@ inline Options parse(int argc, char **argv)
             o.seed = (unsigned)std::strtoul(next("--seed").c_str(), nullptr, 0);
         else if (s == "--no-baselines")
             o.baselines = false;
+        else if (s == "--variant")
+        {
+            const std::string v = next("--variant");
+            o.variant           = -1;
+            for (int k = 0; k < SF_NUM_VARIANTS; ++k)
+                if (v == sf_variant_name(k))
+                    o.variant = k;
+            if (o.variant < 0)
+            {
+                std::cerr << "unknown --variant " << v << std::endl;
+                std::exit(1);
+            }
+        }
         else if (s.rfind("--", 0) == 0)
             ; // unknown --flags are tolerated (the reference let Kokkos::initialize eat them)
         else

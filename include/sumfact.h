@@ -49,7 +49,8 @@ enum
     SF_VARIANT_BLOCK_LDS  = 3, /* one workgroup per element, 3 sweeps in LDS (cf. :291-429)       */
     SF_VARIANT_BLOCK_GLB  = 4, /* one workgroup per element, global workspace (cf. :203-289)       */
     SF_VARIANT_GENERIC    = 5, /* runtime-nq fallback (anisotropic nq0 != nq1 != nq2)              */
-    SF_VARIANT_MFMA       = 6, /* wave kernel with v_mfma_f64_16x16x4 sweeps (high order)          */
+    SF_VARIANT_MFMA       = 6, /* v_mfma_f64_16x16x4 chained GEMMs: 2D quad nq 11..32 (3D: not built, */
+                               /* every 3D order <= 10 is HBM-bound on the wave kernel)            */
     SF_NUM_VARIANTS       = 7
 };
 
@@ -68,7 +69,7 @@ int sf_bwdtrans_hex_f64(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
                         const double *in, double *out, void *stream);
 
 /* Same, with an explicit strategy; wsp (may be NULL) is only used by SF_VARIANT_BLOCK_GLB and
- * must then hold nelmt*(nq0*nm1*nm2 + nq0*nq1*nm2) doubles (benchmark05.cc:1243-1244). */
+ * SF_VARIANT_THREAD and must then hold nelmt*(nq0*nm1*nm2 + nq0*nq1*nm2) doubles (benchmark05.cc:1243-1244). */
 int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
                                 size_t nelmt, const double *basis0, const double *basis1,
                                 const double *basis2, const double *in, double *wsp, double *out,

@@ -69,6 +69,29 @@ def test_quad_wave_parity_all_orders(sf, oracle, nq):
         assert err <= TOL, (nq, nelmt, err)
 
 
+@pytest.mark.parametrize("nq", range(11, 33))
+def test_quad_mfma_parity_all_orders(sf, oracle, nq):
+    """Matrix-core kernel (v_mfma_f64_16x16x4), every order it is built for, ragged counts."""
+    for nelmt in (1, 2, 3, 7, 64, 129, 1000):
+        err = _quad_case(sf, oracle, (nq, nq), nelmt, "mfma", seed=nelmt + nq)
+        assert err <= TOL, (nq, nelmt, err)
+        err = _quad_case(sf, oracle, (nq, nq), nelmt, "auto", seed=nelmt)
+        assert err <= TOL, (nq, nelmt, err)
+
+
+def test_mfma_not_built_cases(sf):
+    capi = sf.capi
+    b = sf.fill_basis(7, 8)
+    x = sf.fill_random(343 * 4, 1)
+    with pytest.raises(capi.SumfactError) as ei:
+        sf.bwdtrans_hex((8, 8, 8), b, b, b, x, variant="mfma")
+    assert ei.value.rc == capi.SF_ENOTBUILT
+    x2 = sf.fill_random(49 * 4, 1)
+    with pytest.raises(capi.SumfactError) as ei:
+        sf.bwdtrans_quad((8, 8), b, b, x2, variant="mfma")
+    assert ei.value.rc == capi.SF_ENOTBUILT
+
+
 @pytest.mark.parametrize("variant", ["auto", "thread", "block-lds", "block-glb", "generic"])
 def test_hex_variants(sf, oracle, variant):
     for nq in [(2, 2, 2), (4, 4, 4), (8, 8, 8), (3, 5, 4), (8, 2, 6), (10, 10, 10), (12, 12, 12)]:
@@ -161,10 +184,6 @@ def test_empty_and_errors(sf, torch_mod):
     with pytest.raises(capi.SumfactError) as ei:
         sf.bwdtrans_hex((1, 8, 8), b, b, b, empty)
     assert ei.value.rc == capi.SF_EINVAL
-    x = sf.fill_random(343 * 4, 1)
-    with pytest.raises(capi.SumfactError) as ei:
-        sf.bwdtrans_hex((8, 8, 8), b, b, b, x, variant="mfma" if False else 6)
-    assert ei.value.rc in (capi.SF_ENOTBUILT, capi.SF_OK)
 
 
 def test_unaligned_input_falls_back(sf, oracle):
