@@ -285,6 +285,86 @@ int oracle_bwdtrans_hex_sweeps(unsigned nq0, unsigned nq1, unsigned nq2, size_t 
     return fail ? -2 : 0;
 }
 
+/*
+ * Same three sweeps, loop order chosen for the CPU (contiguous i innermost so the compiler
+ * vectorises; intermediates w1[r][q][i], w2[r][j][i]).  Every output is still the ascending-p /
+ * ascending-q / ascending-r sum starting from 0.0 of benchmark05.cc:361-423, so without FMA
+ * contraction the result is bit-identical to oracle_bwdtrans_hex_sweeps.  This is the form timed as
+ * the CPU baseline (bench.py cpu_baseline, kind "port").
+ */
+int oracle_bwdtrans_hex_vector(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                               const double *basis0, const double *basis1, const double *basis2,
+                               const double *in, double *out)
+{
+    if (nq0 < 2 || nq1 < 2 || nq2 < 2)
+        return -1;
+    const size_t nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
+    const size_t nm_tot = nm0 * nm1 * nm2, nq_tot = (size_t)nq0 * nq1 * nq2;
+    int fail = 0;
+#pragma omp parallel
+    {
+        double *w1 = (double *)malloc(sizeof(double) * nm2 * nm1 * nq0);
+        double *w2 = (double *)malloc(sizeof(double) * nm2 * nq1 * nq0);
+        if (!w1 || !w2)
+        {
+#pragma omp atomic write
+            fail = 1;
+        }
+        else
+        {
+#pragma omp for schedule(static)
+            for (size_t e = 0; e < nelmt; ++e)
+            {
+                const double *ine = in + nm_tot * e;
+                double *oute      = out + nq_tot * e;
+                for (size_t rq = 0; rq < nm2 * nm1; ++rq)
+                {
+                    double *dst = w1 + rq * nq0;
+                    for (size_t i = 0; i < nq0; ++i)
+                        dst[i] = 0.0;
+                    for (size_t p = 0; p < nm0; ++p)
+                    {
+                        const double u = ine[rq * nm0 + p];
+                        for (size_t i = 0; i < nq0; ++i)
+                            dst[i] += u * basis0[p * nq0 + i];
+                    }
+                }
+                for (size_t r = 0; r < nm2; ++r)
+                    for (size_t j = 0; j < nq1; ++j)
+                    {
+                        double *dst = w2 + (r * nq1 + j) * nq0;
+                        for (size_t i = 0; i < nq0; ++i)
+                            dst[i] = 0.0;
+                        for (size_t q = 0; q < nm1; ++q)
+                        {
+                            const double b   = basis1[q * nq1 + j];
+                            const double *src = w1 + (r * nm1 + q) * nq0;
+                            for (size_t i = 0; i < nq0; ++i)
+                                dst[i] += src[i] * b;
+                        }
+                    }
+                for (size_t k = 0; k < nq2; ++k)
+                    for (size_t j = 0; j < nq1; ++j)
+                    {
+                        double *dst = oute + (k * nq1 + j) * nq0;
+                        for (size_t i = 0; i < nq0; ++i)
+                            dst[i] = 0.0;
+                        for (size_t r = 0; r < nm2; ++r)
+                        {
+                            const double b   = basis2[r * nq2 + k];
+                            const double *src = w2 + (r * nq1 + j) * nq0;
+                            for (size_t i = 0; i < nq0; ++i)
+                                dst[i] += src[i] * b;
+                        }
+                    }
+            }
+        }
+        free(w1);
+        free(w2);
+    }
+    return fail ? -2 : 0;
+}
+
 /* ---------------------------------------------------------------- 2D quad --------------------- */
 
 /* Fused nest (benchmark04.cc:49-72): in[e][q][p] -> out[e][j][i]; scratch wsp[nm1]. */

@@ -46,7 +46,8 @@ def _lib(fast=False):
         lib.oracle_fill_l2norm.argtypes = [_c_dp, sz]
         lib.oracle_sumsq.argtypes = [_c_dp, sz]
         lib.oracle_sumsq.restype = dbl
-        for name in ("oracle_bwdtrans_hex_fused", "oracle_bwdtrans_hex_sweeps"):
+        for name in ("oracle_bwdtrans_hex_fused", "oracle_bwdtrans_hex_sweeps",
+                     "oracle_bwdtrans_hex_vector"):
             f = getattr(lib, name)
             f.argtypes = [u32, u32, u32, sz, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
             f.restype = ctypes.c_int
@@ -145,7 +146,8 @@ def sumsq(x, fast=False):
 # ---------------------------------------------------------------- BwdTrans ---------------------
 
 def bwdtrans_hex(nq, nelmt, b0, b1, b2, inp, form="sweeps", fast=False):
-    """3D hex BwdTrans.  form='fused' -> benchmark05.cc:57-101, 'sweeps' -> :361-423."""
+    """3D hex BwdTrans.  form='fused' -> benchmark05.cc:57-101, 'sweeps' -> :361-423,
+    'vector' -> the same sweeps in a CPU-vectorisable loop order (the timed CPU baseline)."""
     nq0, nq1, nq2 = nq
     out = np.empty(nelmt * nq0 * nq1 * nq2, dtype=np.float64)
     f = getattr(_lib(fast), "oracle_bwdtrans_hex_" + form)

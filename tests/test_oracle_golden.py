@@ -79,6 +79,8 @@ def test_forms_agree_and_match_numpy(oracle):
         s = oracle.bwdtrans_hex(nq, nelmt, *b, x, form="sweeps")
         e = oracle.bwdtrans_hex_numpy(nq, nelmt, *b, x)
         assert np.array_equal(a, s)  # same products, same summation order per dot product
+        v = oracle.bwdtrans_hex(nq, nelmt, *b, x, form="vector")
+        assert np.array_equal(a, v)  # CPU-friendly loop order, still the same sums
         assert oracle.rel_err(a, e) < 1e-13
     for nq in [(2, 2), (5, 5), (8, 8), (32, 32), (4, 9), (16, 3)]:
         nm = tuple(q - 1 for q in nq)
@@ -100,6 +102,8 @@ def test_fast_build_matches_parity_build(oracle):
     a = oracle.bwdtrans_hex(nq, nelmt, b, b, b, x)
     f = oracle.bwdtrans_hex(nq, nelmt, b, b, b, x, fast=True)
     assert oracle.rel_err(f, a) < 1e-14
+    v = oracle.bwdtrans_hex(nq, nelmt, b, b, b, x, form="vector", fast=True)
+    assert oracle.rel_err(v, a) < 1e-14
 
 
 def test_random_generator_pinned(oracle):
