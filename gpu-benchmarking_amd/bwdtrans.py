@@ -152,6 +152,44 @@ def stream_copy(src, dst, stream=None):
     return dst
 
 
+def fill_vecadd(n, device="cuda", stream=None):
+    """benchmark02 data (benchmark02/benchmark02.cc:84-85) -> (x, y)."""
+    x = torch.empty(n, dtype=torch.float64, device=device)
+    y = torch.empty(n, dtype=torch.float64, device=device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().sf_fill_vecadd_f64(_dev_f64(x, "x"), _dev_f64(y, "y"), n,
+                                                 _stream(stream)), "sf_fill_vecadd_f64")
+    return x, y
+
+
+def vector_add(x, y, stream=None):
+    """x += y in place (benchmark02's operation)."""
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().sf_vector_add_f64(_dev_f64(x, "x"), _dev_f64(y, "y"), x.numel(),
+                                                _stream(stream)), "sf_vector_add_f64")
+    return x
+
+
+def fill_matvec(m, n, device="cuda", stream=None):
+    """benchmark03 data -> (A row-major m*n, x)."""
+    a = torch.empty(m * n, dtype=torch.float64, device=device)
+    x = torch.empty(n, dtype=torch.float64, device=device)
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().sf_fill_matvec_f64(_dev_f64(a, "A"), _dev_f64(x, "x"), m, n,
+                                                 _stream(stream)), "sf_fill_matvec_f64")
+    return a, x
+
+
+def matvec(m, n, a, x, y=None, stream=None):
+    """y = A x (benchmark03's operation)."""
+    if y is None:
+        y = torch.empty(m, dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().sf_matvec_f64(m, n, _dev_f64(a, "A"), _dev_f64(x, "x"),
+                                            _dev_f64(y, "y"), _stream(stream)), "sf_matvec_f64")
+    return y
+
+
 def device_info():
     cu, wave = ctypes.c_int(0), ctypes.c_int(0)
     name = ctypes.create_string_buffer(256)

@@ -30,6 +30,10 @@ SYMBOLS = {
     "sf_fill_random_f64": (_i, [_vp, _sz, _u64, _u64, _vp]),
     "sf_fill_l2norm_f64": (_i, [_vp, _sz, _vp]),
     "sf_stream_copy_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "sf_vector_add_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "sf_fill_vecadd_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "sf_matvec_f64": (_i, [_u, _u, _vp, _vp, _vp, _vp]),
+    "sf_fill_matvec_f64": (_i, [_vp, _vp, _u, _u, _vp]),
     "sf_device_info": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "sf_shutdown": (_i, []),
 }

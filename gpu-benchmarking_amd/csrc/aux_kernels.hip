@@ -7,7 +7,9 @@
 //                              oracle_fill_random so host and device arrays agree bit for bit)
 //   sumsq                    : thrust::transform_reduce(x*x, plus) of benchmark05.cc:1273-1276 and the
 //                              l2norm kernels of benchmark01/benchmark01.cc:15-77, 112-169
-//   stream_copy              : bandwidth calibrator (cf. benchmark02/benchmark02.cc:16-58)
+//   stream_copy              : bandwidth calibrator
+//   vector_add / fill_vecadd : benchmark02 (x += y; benchmark02/benchmark02.cc:16-58, data :84-85)
+//   matvec / fill_matvec     : benchmark03 (y = A x; benchmark03/benchmark03.cc:15-104, data :160-167)
 #include "sf_common.h"
 
 #include <mutex>
@@ -162,6 +164,105 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const double2_t *__res
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+}
+
+// One 16-byte lane per thread and a grid that covers the whole array (no grid-stride loop): on this
+// part a dispatcher-ordered huge grid streams ~6.6 TB/s where a persistent grid-stride copy tops out
+// at ~5.7 TB/s (profiles/r01/membench1.log).
+__global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2_t *__restrict__ src,
+                                                               double2_t *__restrict__ dst,
+                                                               uint64_t nv)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < nv)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+}
+
+// x += y (benchmark02's kernel): 16 B of x and y in, 16 B of x out per thread
+__global__ __launch_bounds__(256) void vector_add_kernel(double *__restrict__ x,
+                                                         const double *__restrict__ y, uint64_t n)
+{
+    const uint64_t v  = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nv = n / 2;
+    if (v < nv)
+    {
+        double2_t *x2       = reinterpret_cast<double2_t *>(x) + v;
+        const double2_t a   = __builtin_nontemporal_load(x2);
+        const double2_t b   = __builtin_nontemporal_load(reinterpret_cast<const double2_t *>(y) + v);
+        __builtin_nontemporal_store(a + b, x2);
+    }
+    else if (v == nv && (n & 1))
+        x[n - 1] += y[n - 1];
+}
+
+__global__ __launch_bounds__(256) void vector_add_scalar_kernel(double *__restrict__ x,
+                                                                const double *__restrict__ y,
+                                                                uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        x[i] += y[i];
+}
+
+__global__ __launch_bounds__(256) void fill_vecadd_kernel(double *__restrict__ x,
+                                                          double *__restrict__ y, uint64_t n)
+{
+#pragma clang fp contract(off) // bit-identical to the host statement
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const uint32_t u = (uint32_t)i;
+        const double t1 = 0.00001 * (double)(u % 100191u), t2 = 0.00003 * (double)(u % 100721u);
+        x[i] = (double)(u % 13u) + (0.2 + t1);
+        y[i] = (double)(u % 8u) + (0.4 + t2);
+    }
+}
+
+// y = A x, A row-major M x N: one wavefront per row, 16-byte lanes over the row, x from cache,
+// wave-64 shuffle tree; summation order fixed by (N, lane) -> deterministic.
+__global__ __launch_bounds__(256) void matvec_kernel(uint32_t M, uint32_t N,
+                                                     const double *__restrict__ A,
+                                                     const double *__restrict__ x,
+                                                     double *__restrict__ y)
+{
+    const int lane     = threadIdx.x & (kWave - 1);
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M)
+        return;
+    const double *a = A + (uint64_t)row * N;
+    double s0 = 0.0, s1 = 0.0;
+    if ((N & 1u) == 0 && (((uintptr_t)A | (uintptr_t)x) & 15u) == 0)
+    {
+        const double2_t *a2 = reinterpret_cast<const double2_t *>(a);
+        const double2_t *x2 = reinterpret_cast<const double2_t *>(x);
+        for (uint32_t v = lane; v < N / 2; v += kWave)
+        {
+            const double2_t p = __builtin_nontemporal_load(a2 + v), q = x2[v];
+            s0 = __builtin_fma(p.x, q.x, s0);
+            s1 = __builtin_fma(p.y, q.y, s1);
+        }
+    }
+    else
+    {
+        for (uint32_t j = lane; j < N; j += kWave)
+            s0 = __builtin_fma(a[j], x[j], s0);
+    }
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0)
+        y[row] = s;
+}
+
+__global__ __launch_bounds__(256) void fill_matvec_kernel(double *__restrict__ A,
+                                                          double *__restrict__ x, uint64_t total,
+                                                          uint32_t N)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    {
+        A[i] = sin((double)(i + 1));
+        if (i < N)
+            x[i] = (double)i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,13 +422,58 @@ int stream_copy(const double *src, double *dst, size_t n, hipStream_t s)
         return SF_OK;
     if ((((uintptr_t)src | (uintptr_t)dst) & 15u) != 0 || (n & 1))
         return SF_EALIGN;
-    const uint64_t nv = n / 2;
-    uint64_t blocks   = (nv + 255) / 256;
-    const uint64_t cap = (uint64_t)device_info().num_cu * 8;
-    if (blocks > cap)
-        blocks = cap;
-    stream_copy_kernel<<<(unsigned)blocks, 256, 0, s>>>(reinterpret_cast<const double2_t *>(src),
-                                                        reinterpret_cast<double2_t *>(dst), nv);
+    const uint64_t nv     = n / 2;
+    const uint64_t blocks = (nv + 255) / 256;
+    if (blocks > 0x7fffffffull)
+        return SF_EINVAL;
+    stream_copy_flat_kernel<<<(unsigned)blocks, 256, 0, s>>>(
+        reinterpret_cast<const double2_t *>(src), reinterpret_cast<double2_t *>(dst), nv);
+    return launch_rc();
+}
+
+int vector_add(double *x, const double *y, size_t n, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0)
+    {
+        const uint64_t blocks = (n / 2 + 1 + 255) / 256;
+        if (blocks > 0x7fffffffull)
+            return SF_EINVAL;
+        vector_add_kernel<<<(unsigned)blocks, 256, 0, s>>>(x, y, n);
+    }
+    else
+    {
+        const uint64_t blocks = (n + 255) / 256;
+        if (blocks > 0x7fffffffull)
+            return SF_EINVAL;
+        vector_add_scalar_kernel<<<(unsigned)blocks, 256, 0, s>>>(x, y, n);
+    }
+    return launch_rc();
+}
+
+int fill_vecadd(double *x, double *y, size_t n, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    fill_vecadd_kernel<<<fill_grid(n), 256, 0, s>>>(x, y, n);
+    return launch_rc();
+}
+
+int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s)
+{
+    if (M == 0)
+        return SF_OK;
+    matvec_kernel<<<(M + 3) / 4, 256, 0, s>>>(M, N, A, x, y);
+    return launch_rc();
+}
+
+int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)M * N;
+    if (total == 0)
+        return SF_OK;
+    fill_matvec_kernel<<<fill_grid(total), 256, 0, s>>>(A, x, total, N);
     return launch_rc();
 }
 

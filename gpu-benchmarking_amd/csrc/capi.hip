@@ -22,6 +22,10 @@ int fill_basis(double *b, size_t nm, size_t nq, hipStream_t s);
 int fill_random(double *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
 int fill_l2norm(double *x, size_t n, hipStream_t s);
 int stream_copy(const double *src, double *dst, size_t n, hipStream_t s);
+int vector_add(double *x, const double *y, size_t n, hipStream_t s);
+int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
+int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
+int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
 int release_workspaces();
 } // namespace sf
 
@@ -234,6 +238,38 @@ int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream)
     if ((!src || !dst) && n)
         return SF_EINVAL;
     return stream_copy(src, dst, n, (hipStream_t)stream);
+}
+
+int sf_vector_add_f64(double *x, const double *y, size_t n, void *stream)
+{
+    if ((!x || !y) && n)
+        return SF_EINVAL;
+    if (!aligned(x, 8) || !aligned(y, 8))
+        return SF_EALIGN;
+    return vector_add(x, y, n, (hipStream_t)stream);
+}
+
+int sf_fill_vecadd_f64(double *x, double *y, size_t n, void *stream)
+{
+    if ((!x || !y) && n)
+        return SF_EINVAL;
+    return fill_vecadd(x, y, n, (hipStream_t)stream);
+}
+
+int sf_matvec_f64(unsigned m, unsigned n, const double *A, const double *x, double *y, void *stream)
+{
+    if ((!A || !x || !y) && m && n)
+        return SF_EINVAL;
+    if (!aligned(A, 8) || !aligned(x, 8) || !aligned(y, 8))
+        return SF_EALIGN;
+    return matvec(m, n, A, x, y, (hipStream_t)stream);
+}
+
+int sf_fill_matvec_f64(double *A, double *x, unsigned m, unsigned n, void *stream)
+{
+    if ((!A || !x) && m && n)
+        return SF_EINVAL;
+    return fill_matvec(A, x, m, n, (hipStream_t)stream);
 }
 
 int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len)

@@ -121,6 +121,21 @@ int sf_fill_l2norm_f64(double *x, size_t n, void *stream);
  */
 int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream);
 
+/*
+ * benchmark02: x[i] += y[i]  -- replaces add_vector<T,vl><<<>>>
+ * (benchmark02/benchmark02.cc:16-58); 24 bytes of HBM traffic per element (:255), so its GB/s is the
+ * measured stream rate used as the second roofline denominator.  fill: data1/data2 of :84-85.
+ */
+int sf_vector_add_f64(double *x, const double *y, size_t n, void *stream);
+int sf_fill_vecadd_f64(double *x, double *y, size_t n, void *stream);
+
+/*
+ * benchmark03: y = A x, A row-major m x n -- replaces compute_matvec<T,vl><<<>>>
+ * (benchmark03/benchmark03.cc:80-104).  fill: A[i*n+j] = sin(i*n+j+1), x[j] = j (:160-167).
+ */
+int sf_matvec_f64(unsigned m, unsigned n, const double *A, const double *x, double *y, void *stream);
+int sf_fill_matvec_f64(double *A, double *x, unsigned m, unsigned n, void *stream);
+
 /* Number of compute units / device name of the current device (for logs). */
 int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len);
 

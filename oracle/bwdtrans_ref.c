@@ -107,6 +107,63 @@ void oracle_fill_l2norm(double *x, size_t n)
     }
 }
 
+/* benchmark02: data1[i] = i%13 + (0.2 + 1e-5*(i%100191)), data2[i] = i%8 + (0.4 + 3e-5*(i%100721))
+ * (benchmark02/benchmark02.cc:84-85); the timed operation is data1 += data2, 40 times (:88-97). */
+void oracle_fill_vecadd(double *x, double *y, size_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i)
+    {
+        unsigned int u = (unsigned int)i;
+        x[i] = u % 13u + (0.2 + 0.00001 * (u % 100191u));
+        y[i] = u % 8u + (0.4 + 0.00003 * (u % 100721u));
+    }
+}
+
+void oracle_vector_add(double *x, const double *y, size_t n, int times)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i)
+    {
+        double v = x[i];
+        for (int t = 0; t < times; ++t)
+            v += y[i];
+        x[i] = v;
+    }
+}
+
+/* benchmark03: A[i*N + j] = sin(i*N + j + 1), x[j] = j (benchmark03/benchmark03.cc:160-167);
+ * y[i] = sum_j A[i][j] * x[j]  (:80-104). */
+void oracle_fill_matvec(double *A, double *x, size_t M, size_t N)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < M; ++i)
+        for (size_t j = 0; j < N; ++j)
+            A[i * N + j] = sin((double)(i * N + j + 1));
+    for (size_t j = 0; j < N; ++j)
+        x[j] = (double)j;
+}
+
+static double dot_pairwise(const double *a, const double *b, size_t n)
+{
+    if (n <= 64)
+    {
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i)
+            s += a[i] * b[i];
+        return s;
+    }
+    size_t h = n / 2;
+    return dot_pairwise(a, b, h) + dot_pairwise(a + h, b + h, n - h);
+}
+
+void oracle_matvec(size_t M, size_t N, const double *A, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < M; ++i)
+        y[i] = dot_pairwise(A + i * N, x, N);
+}
+
 /* ---------------------------------------------------------------- reductions ------------------ */
 
 /* Pairwise (cascade) sum of squares: error O(log n * eps), independent of thread count. */

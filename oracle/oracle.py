@@ -44,6 +44,10 @@ def _lib(fast=False):
         lib.oracle_random_value.argtypes = [u64, u64]
         lib.oracle_random_value.restype = dbl
         lib.oracle_fill_l2norm.argtypes = [_c_dp, sz]
+        lib.oracle_fill_vecadd.argtypes = [_c_dp, _c_dp, sz]
+        lib.oracle_vector_add.argtypes = [_c_dp, _c_dp, sz, ctypes.c_int]
+        lib.oracle_fill_matvec.argtypes = [_c_dp, _c_dp, sz, sz]
+        lib.oracle_matvec.argtypes = [sz, sz, _c_dp, _c_dp, _c_dp]
         lib.oracle_sumsq.argtypes = [_c_dp, sz]
         lib.oracle_sumsq.restype = dbl
         for name in ("oracle_bwdtrans_hex_fused", "oracle_bwdtrans_hex_sweeps",
@@ -135,6 +139,33 @@ def fill_l2norm(n):
     a = np.empty(n, dtype=np.float64)
     _lib().oracle_fill_l2norm(_p(a), n)
     return a
+
+
+def fill_vecadd(n):
+    """benchmark02 data (benchmark02/benchmark02.cc:84-85)."""
+    x, y = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.float64)
+    _lib().oracle_fill_vecadd(_p(x), _p(y), n)
+    return x, y
+
+
+def vector_add(x, y, times=1):
+    """x += y, `times` times, in place (benchmark02/benchmark02.cc:88-97 runs it 40 times)."""
+    _lib().oracle_vector_add(_p(x), _p(y), x.size, times)
+    return x
+
+
+def fill_matvec(m, n):
+    """benchmark03 data: A[i][j] = sin(i*N+j+1), x[j] = j (benchmark03/benchmark03.cc:160-167)."""
+    a, x = np.empty(m * n, dtype=np.float64), np.empty(n, dtype=np.float64)
+    _lib().oracle_fill_matvec(_p(a), _p(x), m, n)
+    return a, x
+
+
+def matvec(m, n, a, x):
+    """y = A x, A row-major m x n (benchmark03/benchmark03.cc:80-104)."""
+    y = np.empty(m, dtype=np.float64)
+    _lib().oracle_matvec(m, n, _p(a), _p(x), _p(y))
+    return y
 
 
 def sumsq(x, fast=False):

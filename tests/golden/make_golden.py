@@ -52,11 +52,16 @@ def main():
                                 "rows": parse(path, "nelmt", 8)}
     path = f"{REF}/benchmark01/outfile.log"
     out["l2norm"] = {"file": os.path.relpath(path, REF), "rows": parse(path, "Size", 1)}
+    path = f"{REF}/benchmark02/outfile.log"
+    out["vecadd"] = {"file": os.path.relpath(path, REF), "rows": parse(path, "Size", 1)}
+    path = f"{REF}/benchmark03/outfile.log"
+    out["matvec"] = {"file": os.path.relpath(path, REF), "rows": parse(path, "Size", 1)}
     # grammar fixtures: the first lines (banner + two sizes) of one log per benchmark, verbatim
     # result data of the reference, used by tests/test_logfmt.py to pin the log grammar
     out["log_excerpts"] = {}
     for rel, nlines in (("benchmark05/nq8x8x8.log", 10), ("benchmark04/nq8x8.log", 10),
-                        ("benchmark01/outfile.log", 9)):
+                        ("benchmark01/outfile.log", 9), ("benchmark02/outfile.log", 9),
+                        ("benchmark03/outfile.log", 9)):
         with open(f"{REF}/{rel}") as fh:
             out["log_excerpts"][rel] = "".join(fh.readlines()[:nlines])
     with open(OUT, "w") as fh:
@@ -64,6 +69,7 @@ def main():
     n = sum(len(v["rows"]) for v in out["hex"].values()) + \
         sum(len(v["rows"]) for v in out["quad"].values()) + len(out["l2norm"]["rows"])
     assert n == 216
+    n += len(out["vecadd"]["rows"]) + len(out["matvec"]["rows"])
     print(f"wrote {OUT}: {n} known-answer values")
 
 

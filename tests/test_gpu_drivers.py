@@ -76,6 +76,21 @@ def test_benchmark01_device_column(pkg, golden):
             assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)]
 
 
+def test_benchmark02_and_03_device_columns(pkg, golden):
+    out = _run([os.path.join(BIN, "benchmark02"), "--max-size", str(1 << 24)])
+    log = pkg.logfmt.parse_log(out)
+    want = {r["n"]: float(r["norm"]) for r in golden["vecadd"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        for v in norms:
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
+    out = _run([os.path.join(BIN, "benchmark03"), "--max-size", "4096"])
+    log = pkg.logfmt.parse_log(out)
+    want = {r["n"]: float(r["norm"]) for r in golden["matvec"]["rows"]}
+    for size, norms in zip(log.sizes, log.norms):
+        for v in norms:
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
+
+
 def test_anisotropic_cli(pkg, oracle):
     """nq0 != nq1 != nq2 takes the generic path; norm checked against the oracle."""
     import math

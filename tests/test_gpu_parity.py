@@ -175,6 +175,43 @@ def test_sumsq(sf, oracle, torch_mod):
     assert abs(sf.sumsq(x[1:]) - oracle.sumsq(_np(x)[1:])) <= 1e-13 * 400
 
 
+def test_vecadd_and_matvec(sf, oracle, golden, torch_mod):
+    """Section 8(f) kernels: benchmark02 x += y (bit-exact vs the host statement, published norm after
+    40 additions, all 20 sizes) and benchmark03 y = A x (<= 1e-12, published norms, all 8 sizes)."""
+    for row in golden["vecadd"]["rows"]:
+        n = row["n"]
+        x, y = sf.fill_vecadd(n)
+        if n <= (1 << 20):
+            xr, yr = oracle.fill_vecadd(n)
+            assert np.array_equal(_np(x), xr) and np.array_equal(_np(y), yr)
+        for _ in range(40):
+            sf.vector_add(x, y)
+        if n <= (1 << 20):
+            assert np.array_equal(_np(x), oracle.vector_add(xr, yr, times=40))
+        ref = float(row["norm"])
+        assert abs(math.sqrt(sf.sumsq(x)) - ref) <= 5.5e-10 * ref, row
+        del x, y
+    # odd length + unaligned views
+    x, y = sf.fill_vecadd(1003)
+    xr, yr = oracle.fill_vecadd(1003)
+    sf.vector_add(x, y)
+    assert np.array_equal(_np(x), oracle.vector_add(xr.copy(), yr, 1))
+    sf.vector_add(x[1:], y[1:])
+    for row in golden["matvec"]["rows"]:
+        n = row["n"]
+        a, x = sf.fill_matvec(n, n)
+        yv = sf.matvec(n, n, a, x)
+        ref = float(row["norm"])
+        assert abs(math.sqrt(sf.sumsq(yv)) - ref) <= 5.5e-10 * ref, row
+        if n <= 2048:
+            yo = oracle.matvec(n, n, _np(a), _np(x))
+            assert oracle.rel_err(_np(yv), yo) <= TOL
+        del a, x, yv
+    a, x = sf.fill_matvec(37, 101)       # odd extents take the 8-byte-lane path
+    yo = oracle.matvec(37, 101, _np(a), _np(x))
+    assert oracle.rel_err(_np(sf.matvec(37, 101, a, x)), yo) <= TOL
+
+
 def test_empty_and_errors(sf, torch_mod):
     capi = sf.capi
     b = sf.fill_basis(7, 8)

@@ -66,6 +66,32 @@ def test_benchmark01_host_path_log(pkg, golden, tmp_path):
     assert js.exists() and '"benchmark": "benchmark01"' in js.read_text()
 
 
+def test_benchmark02_and_03_host_paths(pkg, golden):
+    """Section 8(f) drivers: same banner/grammar contract, host columns reproduce the published norms."""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    res = subprocess.run([os.path.join(BIN, "benchmark02"), "--max-size", str(1 << 18)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.splitlines()[1] == "Benchmark02 : Vector Addition   "
+    log = pkg.logfmt.parse_log(res.stdout)
+    want = {r["n"]: float(r["norm"]) for r in golden["vecadd"]["rows"]}
+    assert log.kind == "GB/s" and log.ncols == 2 and len(log.sizes) == 9
+    for size, norms in zip(log.sizes, log.norms):
+        assert abs(norms[0] - want[int(size)]) <= 5.5e-10 * want[int(size)]
+    res = subprocess.run([os.path.join(BIN, "benchmark03"), "--max-size", "1024"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.splitlines()[1] == "Benchmark03 : Matrix-Vector Mult"
+    log = pkg.logfmt.parse_log(res.stdout)
+    want = {r["n"]: float(r["norm"]) for r in golden["matvec"]["rows"]}
+    assert log.sizes == [128.0, 256.0, 512.0, 1024.0]
+    for size, norms in zip(log.sizes, log.norms):
+        assert abs(norms[0] - want[int(size)]) <= 5.5e-10 * want[int(size)]
+    ref2 = pkg.logfmt.parse_log(golden["log_excerpts"]["benchmark02/outfile.log"])
+    ref3 = pkg.logfmt.parse_log(golden["log_excerpts"]["benchmark03/outfile.log"])
+    assert ref2.ncols == 5 and ref3.ncols == 5 and ref3.sizes[0] == 128.0
+
+
 def test_postprocess_plots(pkg, golden, tmp_path):
     pytest.importorskip("matplotlib")
     import importlib

@@ -68,6 +68,33 @@ def test_l2norm_norms(golden, oracle):
         assert _sig10(math.sqrt(oracle.sumsq(x)), row["norm"]), row
 
 
+def test_vecadd_norms(golden, oracle):
+    """benchmark02: after the 40 timed in-place additions, sqrt(sum data1^2) as published."""
+    rows = golden["vecadd"]["rows"]
+    assert len(rows) == 20
+    for row in rows:
+        n = row["n"]
+        if n > (1 << 22):
+            continue
+        x, y = oracle.fill_vecadd(n)
+        oracle.vector_add(x, y, times=40)
+        assert _sig10(math.sqrt(oracle.sumsq(x)), row["norm"]), row
+
+
+def test_matvec_norms(golden, oracle):
+    rows = golden["matvec"]["rows"]
+    assert len(rows) == 8
+    for row in rows:
+        n = row["n"]
+        if n > 4096:
+            continue
+        a, x = oracle.fill_matvec(n, n)
+        y = oracle.matvec(n, n, a, x)
+        assert _sig10(math.sqrt(oracle.sumsq(y)), row["norm"]), row
+        if n <= 1024:
+            assert oracle.rel_err(y, a.reshape(n, n) @ x) < 1e-12
+
+
 def test_forms_agree_and_match_numpy(oracle):
     """fused nest == 3-sweep form == independent einsum, on per-element-distinct data."""
     for nq in [(2, 2, 2), (3, 3, 3), (4, 4, 4), (8, 8, 8), (10, 10, 10), (3, 5, 4), (8, 2, 6)]:
