@@ -180,6 +180,12 @@ def main():
             del xs, os_
         if not args.no_extra:
             result["extra"] = extras(sf, torch, dev)
+            # second denominator: the device's own measured stream rate (benchmark02's x += y,
+            # 24 B/element), next to the 8 TB/s datasheet figure
+            stream = measured_stream_gbs(sf, torch, dev)
+            result["roofline"]["measured_stream_gb_s"] = round(stream, 1)
+            result["roofline"]["frac_of_measured_stream"] = round(
+                result["roofline"]["achieved"] / stream, 4)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(nq, args.cpu_seconds)
             result["vs_reference_published"] = {
@@ -191,6 +197,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_stream_gbs(sf, torch, dev, n=1 << 28, reps=10):
+    """benchmark02 on this device: x += y over 2 x 2 GiB, best of `reps` (HIP events)."""
+    x, y = sf.fill_vecadd(n, dev)
+    sf.vector_add(x, y)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sf.vector_add(x, y)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return 24.0 * n / best * 1e-6
 
 
 def extras(sf, torch, dev, nelmt=1 << 20, reps=10):

@@ -9,7 +9,8 @@
 //   1 HIP (thread/elmt)     decomposition of BwdTransQuadKernel        (:15-76)
 //   2 HIP (block/elmt glb)  BwdTransQuadKernel_QP_1D, global wsp       (:302-351)
 //   3 HIP (block/elmt LDS)  BwdTransQuadKernel_QP_1D, shared           (:353-426)
-//   4 HIP (wave/chunk)      flagship (sf_bwdtrans_quad_f64)
+//   4 HIP (wave/chunk)      flagship (sf_bwdtrans_quad_f64; matrix cores from nq = 13)
+//   5 rocBLAS               1 DGEMM + 1 strided-batched DGEMM, global wsp (cuBLAS column :750-836)
 // Extra options AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4).
 #include "harness.h"
@@ -44,12 +45,16 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     SF_CHECK(sf_fill_basis_f64(d_basis1.get(), nm1, nq1, nullptr));
     HIP_CHECK(hipDeviceSynchronize());
 
-    const int variants[4] = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
-                             g_opt.variant};
-    const char *names[4]  = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
-                             "HIP (wave/chunk)"};
-    double times[4], results[4];
-    for (int v = 0; v < 4; ++v)
+    constexpr int NCOL       = 5;
+    const int variants[NCOL] = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
+                                g_opt.variant, -1 /* rocBLAS */};
+    const char *names[NCOL]  = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                                "HIP (wave/chunk)", "rocBLAS"};
+    double times[NCOL], results[NCOL];
+#ifdef SF_WITH_ROCBLAS
+    static RocblasColumn blas;
+#endif
+    for (int v = 0; v < NCOL; ++v)
     {
         times[v]   = std::numeric_limits<double>::max();
         results[v] = 0.0;
@@ -58,28 +63,41 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
         HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
         auto launch = [&]()
         {
-            SF_CHECK(sf_bwdtrans_quad_f64_variant(variants[v], nq0, nq1, nelmt, d_basis0.get(),
-                                                  d_basis1.get(), d_in.get(), d_wsp.get(),
-                                                  d_out.get(), nullptr));
+            if (variants[v] >= 0)
+                SF_CHECK(sf_bwdtrans_quad_f64_variant(variants[v], nq0, nq1, nelmt, d_basis0.get(),
+                                                      d_basis1.get(), d_in.get(), d_wsp.get(),
+                                                      d_out.get(), nullptr));
+#ifdef SF_WITH_ROCBLAS
+            else
+                blas.quad(nq0, nq1, nelmt, d_basis0.get(), d_basis1.get(), d_in.get(), d_wsp.get(),
+                          d_out.get());
+#endif
         };
+#ifdef SF_WITH_ROCBLAS
+        if (variants[v] < 0 && !blas.ok())
+            continue;
+#else
+        if (variants[v] < 0)
+            continue;
+#endif
         launch();
         HIP_CHECK(hipDeviceSynchronize());
-        times[v] = time_min(launch, v == 3 ? 1e30 : kSlowBudgetS);
+        times[v] = time_min(launch, v >= 3 ? 1e30 : kSlowBudgetS);
         SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
     }
 
     // Display results (grammar of benchmark04.cc:1022-1055)
     std::cout << std::setprecision(10);
     std::cout << "nelmt " << nelmt << " Case:";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
         std::cout << " " << names[v];
     std::cout << std::endl;
     std::cout << "nelmt " << nelmt << " norm: ";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
         std::cout << (v ? "     " : "") << std::sqrt(results[v]);
     std::cout << std::endl;
     std::cout << "nelmt " << nelmt << " DOF/s: ";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
     {
         const double dofs = times[v] < 1e300 ? 1.0e-9 * nelmt * (double)nmTot / times[v] : 0.0;
         std::cout << (v ? "     " : "") << dofs;

@@ -11,6 +11,7 @@
 //   2 HIP (block/elmt glb)  one workgroup per element, global wsp     (:431-508)
 //   3 HIP (block/elmt LDS)  one workgroup per element, all in LDS     (:510-617)
 //   4 HIP (wave/chunk)      flagship: one wavefront streams chunks    (sf_bwdtrans_hex_f64)
+//   5 rocBLAS               1 DGEMM + 2 strided-batched DGEMMs, global wsp (cuBLAS column :1062-1171)
 // `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4).
@@ -47,12 +48,16 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     SF_CHECK(sf_fill_basis_f64(d_basis2.get(), nm2, nq2, nullptr));
     HIP_CHECK(hipDeviceSynchronize());
 
-    const int variants[4]  = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
-                              g_opt.variant};
-    const char *names[4]   = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
-                              "HIP (wave/chunk)"};
-    double times[4], results[4];
-    for (int v = 0; v < 4; ++v)
+    constexpr int NCOL        = 5;
+    const int variants[NCOL]  = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
+                                 g_opt.variant, -1 /* rocBLAS */};
+    const char *names[NCOL]   = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                                 "HIP (wave/chunk)", "rocBLAS"};
+    double times[NCOL], results[NCOL];
+#ifdef SF_WITH_ROCBLAS
+    static RocblasColumn blas;
+#endif
+    for (int v = 0; v < NCOL; ++v)
     {
         times[v]   = std::numeric_limits<double>::max();
         results[v] = 0.0;
@@ -61,28 +66,41 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
         HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
         auto launch = [&]()
         {
-            SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt, d_basis0.get(),
-                                                 d_basis1.get(), d_basis2.get(), d_in.get(),
-                                                 d_wsp.get(), d_out.get(), nullptr));
+            if (variants[v] >= 0)
+                SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
+                                                     d_basis0.get(), d_basis1.get(), d_basis2.get(),
+                                                     d_in.get(), d_wsp.get(), d_out.get(), nullptr));
+#ifdef SF_WITH_ROCBLAS
+            else
+                blas.hex(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(), d_basis2.get(),
+                         d_in.get(), d_wsp.get(), d_out.get());
+#endif
         };
+#ifdef SF_WITH_ROCBLAS
+        if (variants[v] < 0 && !blas.ok())
+            continue;
+#else
+        if (variants[v] < 0)
+            continue;
+#endif
         launch(); // first touch outside the timed loop
         HIP_CHECK(hipDeviceSynchronize());
-        times[v] = time_min(launch, v == 3 ? 1e30 : kSlowBudgetS);
+        times[v] = time_min(launch, v >= 3 ? 1e30 : kSlowBudgetS);
         SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
     }
 
     // Display results (grammar of benchmark05.cc:1387-1420)
     std::cout << std::setprecision(10);
     std::cout << "nelmt " << nelmt << " Case:";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
         std::cout << " " << names[v];
     std::cout << std::endl;
     std::cout << "nelmt " << nelmt << " norm: ";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
         std::cout << (v ? "     " : "") << std::sqrt(results[v]);
     std::cout << std::endl;
     std::cout << "nelmt " << nelmt << " DOF/s: ";
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NCOL; ++v)
     {
         const double dofs = times[v] < 1e300 ? 1.0e-9 * nelmt * (double)nmTot / times[v] : 0.0;
         std::cout << (v ? "     " : "") << dofs;

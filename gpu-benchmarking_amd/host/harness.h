@@ -22,6 +22,10 @@
 #include "sumfact.h"
 #include "timer.h"
 
+#ifdef SF_WITH_ROCBLAS
+#include <rocblas/rocblas.h>
+#endif
+
 #define HIP_CHECK(expr)                                                                            \
     do                                                                                             \
     {                                                                                              \
@@ -210,6 +214,78 @@ struct JsonLog
         std::fclose(f);
     }
 };
+
+#ifdef SF_WITH_ROCBLAS
+// Vendor-library column, counterpart of the reference's cuBLAS column
+// (benchmark05/benchmark05.cc:1062-1171, benchmark04/benchmark04.cc:750-836): the sweeps as library
+// GEMMs with the intermediates in a global workspace.  Formulated for THIS build's layouts
+// (in[e][r][q][p], out[e][k][j][i]); column-major BLAS view, bases row-major nm x nq = col-major nq x nm:
+//   dir 0  W1[nq0 x (nm1 nm2 nelmt)]      = B0cm (nq0 x nm0) * IN (nm0 x nm1 nm2 nelmt)      one DGEMM
+//   dir 1  W2_(e,r)[nq0 x nq1]            = W1_(e,r) (nq0 x nm1) * B1cm^T                    batched over (e,r)
+//   dir 2  OUT_e[(nq0 nq1) x nq2]         = W2_e ((nq0 nq1) x nm2) * B2cm^T                  batched over e
+struct RocblasColumn
+{
+    rocblas_handle handle = nullptr;
+    RocblasColumn()
+    {
+        if (rocblas_create_handle(&handle) != rocblas_status_success)
+            handle = nullptr;
+    }
+    ~RocblasColumn()
+    {
+        if (handle)
+            rocblas_destroy_handle(handle);
+    }
+    bool ok() const
+    {
+        return handle != nullptr;
+    }
+    static void check(rocblas_status st, const char *what)
+    {
+        if (st != rocblas_status_success)
+        {
+            std::cerr << "rocBLAS error " << (int)st << " in " << what << std::endl;
+            std::exit(5);
+        }
+    }
+    void hex(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt, const double *b0,
+             const double *b1, const double *b2, const double *in, double *wsp, double *out)
+    {
+        const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
+        const double one = 1.0, zero = 0.0;
+        double *w1 = wsp, *w2 = wsp + nelmt * (size_t)nq0 * nm1 * nm2;
+        check(rocblas_dgemm(handle, rocblas_operation_none, rocblas_operation_none, nq0,
+                            (rocblas_int)(nelmt * nm1 * nm2), nm0, &one, b0, nq0, in, nm0, &zero, w1,
+                            nq0),
+              "dgemm dir0");
+        check(rocblas_dgemm_strided_batched(handle, rocblas_operation_none, rocblas_operation_transpose,
+                                            nq0, nq1, nm1, &one, w1, nq0, (rocblas_stride)nq0 * nm1, b1,
+                                            nq1, 0, &zero, w2, nq0, (rocblas_stride)nq0 * nq1,
+                                            (rocblas_int)(nelmt * nm2)),
+              "dgemm_strided_batched dir1");
+        check(rocblas_dgemm_strided_batched(handle, rocblas_operation_none, rocblas_operation_transpose,
+                                            nq0 * nq1, nq2, nm2, &one, w2, nq0 * nq1,
+                                            (rocblas_stride)nq0 * nq1 * nm2, b2, nq2, 0, &zero, out,
+                                            nq0 * nq1, (rocblas_stride)nq0 * nq1 * nq2,
+                                            (rocblas_int)nelmt),
+              "dgemm_strided_batched dir2");
+    }
+    void quad(unsigned nq0, unsigned nq1, size_t nelmt, const double *b0, const double *b1,
+              const double *in, double *wsp, double *out)
+    {
+        const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1;
+        const double one = 1.0, zero = 0.0;
+        check(rocblas_dgemm(handle, rocblas_operation_none, rocblas_operation_none, nq0,
+                            (rocblas_int)(nelmt * nm1), nm0, &one, b0, nq0, in, nm0, &zero, wsp, nq0),
+              "dgemm dir0");
+        check(rocblas_dgemm_strided_batched(handle, rocblas_operation_none, rocblas_operation_transpose,
+                                            nq0, nq1, nm1, &one, wsp, nq0, (rocblas_stride)nq0 * nm1, b1,
+                                            nq1, 0, &zero, out, nq0, (rocblas_stride)nq0 * nq1,
+                                            (rocblas_int)nelmt),
+              "dgemm_strided_batched dir1");
+    }
+};
+#endif
 
 inline std::string device_header()
 {

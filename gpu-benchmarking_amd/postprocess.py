@@ -23,8 +23,8 @@ except ImportError:  # run as a script
     import logfmt
 
 OUR_LABELS = {
-    ("DOF/s", 4): ["HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
-                   "HIP (wave/chunk)"],
+    ("DOF/s", 5): ["HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                   "HIP (wave/chunk)", "rocBLAS"],
     ("GB/s", 2): ["Host (OpenMP)", "HIP (vl)"],
 }
 REFERENCE_LABELS = {
