@@ -21,11 +21,14 @@ def _stream(stream):
     return ctypes.c_void_p(stream.cuda_stream)
 
 
-def _dev_f64(t, name):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64
-            and t.is_contiguous()):
-        raise TypeError(f"{name} must be a contiguous float64 CUDA/HIP tensor")
+def _dev_f64(t, name, dtype=torch.float64):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous {dtype} CUDA/HIP tensor")
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, name):
+    return _dev_f64(t, name, torch.float32)
 
 
 def _variant(v):
@@ -54,9 +57,17 @@ def bwdtrans_hex(nq, basis0, basis1, basis2, inp, out=None, variant="auto", wsp=
     if nelmt * nmt != inp.numel():
         raise ValueError("in.numel() is not a multiple of nm0*nm1*nm2")
     if out is None:
-        out = torch.empty(nelmt * nq0 * nq1 * nq2, dtype=torch.float64, device=inp.device)
+        out = torch.empty(nelmt * nq0 * nq1 * nq2, dtype=inp.dtype, device=inp.device)
     elif out.numel() != nelmt * nq0 * nq1 * nq2:
         raise ValueError("out has the wrong size")
+    if inp.dtype == torch.float32:      # T = float instantiation; AUTO strategy only
+        with torch.cuda.device(inp.device):
+            rc = capi.lib().sf_bwdtrans_hex_f32(
+                nq0, nq1, nq2, nelmt, _dev_f32(basis0, "basis0"), _dev_f32(basis1, "basis1"),
+                _dev_f32(basis2, "basis2"), _dev_f32(inp, "in"), _dev_f32(out, "out"),
+                _stream(stream))
+        capi.check(rc, "sf_bwdtrans_hex_f32")
+        return out
     v = _variant(variant)
     if wsp is None and v in (2, 4) and nelmt:
         wsp = torch.empty(hex_wsp_doubles((nq0, nq1, nq2), nelmt), dtype=torch.float64,
@@ -81,9 +92,16 @@ def bwdtrans_quad(nq, basis0, basis1, inp, out=None, variant="auto", wsp=None, s
     if nelmt * nmt != inp.numel():
         raise ValueError("in.numel() is not a multiple of nm0*nm1")
     if out is None:
-        out = torch.empty(nelmt * nq0 * nq1, dtype=torch.float64, device=inp.device)
+        out = torch.empty(nelmt * nq0 * nq1, dtype=inp.dtype, device=inp.device)
     elif out.numel() != nelmt * nq0 * nq1:
         raise ValueError("out has the wrong size")
+    if inp.dtype == torch.float32:
+        with torch.cuda.device(inp.device):
+            rc = capi.lib().sf_bwdtrans_quad_f32(
+                nq0, nq1, nelmt, _dev_f32(basis0, "basis0"), _dev_f32(basis1, "basis1"),
+                _dev_f32(inp, "in"), _dev_f32(out, "out"), _stream(stream))
+        capi.check(rc, "sf_bwdtrans_quad_f32")
+        return out
     v = _variant(variant)
     if wsp is None and v in (2, 4) and nelmt:
         wsp = torch.empty(quad_wsp_doubles((nq0, nq1), nelmt), dtype=torch.float64,
@@ -101,40 +119,47 @@ def sumsq(x, stream=None):
     """sum x^2 (blocking; deterministic) -- the reference's thrust::transform_reduce."""
     res = ctypes.c_double(0.0)
     with torch.cuda.device(x.device):
-        rc = capi.lib().sf_sumsq_f64(_dev_f64(x, "x"), x.numel(), ctypes.byref(res),
-                                     _stream(stream))
-    capi.check(rc, "sf_sumsq_f64")
+        if x.dtype == torch.float32:
+            rc = capi.lib().sf_sumsq_f32(_dev_f32(x, "x"), x.numel(), ctypes.byref(res),
+                                         _stream(stream))
+        else:
+            rc = capi.lib().sf_sumsq_f64(_dev_f64(x, "x"), x.numel(), ctypes.byref(res),
+                                         _stream(stream))
+    capi.check(rc, "sf_sumsq")
     return res.value
 
 
-def _filled(n, device, call, what):
-    x = torch.empty(n, dtype=torch.float64, device=device)
+def _filled(n, device, call, what, dtype=torch.float64):
+    x = torch.empty(n, dtype=dtype, device=device)
     with torch.cuda.device(x.device):
-        capi.check(call(_dev_f64(x, "x")), what)
+        capi.check(call(ctypes.c_void_p(x.data_ptr())), what)
     return x
 
 
-def fill_sincos(nelmt, nm_tot, device="cuda", stream=None):
-    """in[e][f] = sin(f+1) (benchmark05/benchmark05.cc:1206-1207), generated on the device."""
-    st = _stream(stream)
-    return _filled(nelmt * nm_tot, device,
-                   lambda p: capi.lib().sf_fill_sincos_f64(p, nelmt, nm_tot, st),
-                   "sf_fill_sincos_f64")
+def _sfx(dtype):
+    if dtype not in (torch.float64, torch.float32):
+        raise TypeError("dtype must be torch.float64 or torch.float32")
+    return "f32" if dtype == torch.float32 else "f64"
 
 
-def fill_basis(nm, nq, device="cuda", stream=None):
-    """basis[x] = cos(x) (benchmark05/benchmark05.cc:1220)."""
-    st = _stream(stream)
-    return _filled(nm * nq, device, lambda p: capi.lib().sf_fill_basis_f64(p, nm, nq, st),
-                   "sf_fill_basis_f64")
+def fill_sincos(nelmt, nm_tot, device="cuda", stream=None, dtype=torch.float64):
+    """in[e][f] = sin((T)(f+1)) (benchmark05/benchmark05.cc:1206-1207), generated on the device."""
+    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_sincos_" + _sfx(dtype))
+    return _filled(nelmt * nm_tot, device, lambda p: fn(p, nelmt, nm_tot, st), "sf_fill_sincos",
+                   dtype)
 
 
-def fill_random(n, seed, first_idx=0, device="cuda", stream=None):
-    """Seeded per-value-distinct U[-1,1) data; bit-identical to oracle.fill_random."""
-    st = _stream(stream)
-    return _filled(n, device,
-                   lambda p: capi.lib().sf_fill_random_f64(p, n, seed, first_idx, st),
-                   "sf_fill_random_f64")
+def fill_basis(nm, nq, device="cuda", stream=None, dtype=torch.float64):
+    """basis[x] = cos((T)x) (benchmark05/benchmark05.cc:1220)."""
+    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_basis_" + _sfx(dtype))
+    return _filled(nm * nq, device, lambda p: fn(p, nm, nq, st), "sf_fill_basis", dtype)
+
+
+def fill_random(n, seed, first_idx=0, device="cuda", stream=None, dtype=torch.float64):
+    """Seeded per-value-distinct U[-1,1) data; bit-identical to oracle.fill_random (rounded to
+    float for dtype=float32)."""
+    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_random_" + _sfx(dtype))
+    return _filled(n, device, lambda p: fn(p, n, seed, first_idx, st), "sf_fill_random", dtype)
 
 
 def fill_l2norm(n, device="cuda", stream=None):

@@ -265,6 +265,59 @@ __global__ __launch_bounds__(256) void fill_matvec_kernel(double *__restrict__ A
     }
 }
 
+// ---- fp32 counterparts (T = float; the reference's templates allow it, benchmark05.cc:15, 1129-1141) -----
+__global__ __launch_bounds__(256) void fill_sincos_f32_kernel(float *__restrict__ in, uint64_t total,
+                                                              uint32_t nm_tot)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride)
+        in[x] = sinf((float)((uint32_t)(x % nm_tot) + 1u)); // sin((T)(f+1)) with T = float
+}
+
+__global__ __launch_bounds__(256) void fill_basis_f32_kernel(float *__restrict__ b, uint32_t n)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n)
+        b[x] = cosf((float)x);
+}
+
+// the fp64 generator's value rounded to float: host and device still agree bit for bit
+__global__ __launch_bounds__(256) void fill_random_f32_kernel(float *__restrict__ x, uint64_t n,
+                                                              uint64_t seed, uint64_t first)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const uint64_t h = mix64(seed ^ mix64(first + i));
+        x[i]             = (float)((double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+    }
+}
+
+// sum of squares of floats, accumulated in double (float accumulation loses the check's digits)
+__global__ __launch_bounds__(kRedThreads) void sumsq_partial_f32_kernel(const float *__restrict__ x,
+                                                                        uint64_t n,
+                                                                        double *__restrict__ part)
+{
+    __shared__ double red[kRedThreads / kWave];
+    const uint64_t stride = (uint64_t)gridDim.x * kRedThreads;
+    double a0 = 0.0, a1 = 0.0;
+    uint64_t i = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride)
+    {
+        const double p = x[i], q = x[i + stride];
+        a0 = __builtin_fma(p, p, a0);
+        a1 = __builtin_fma(q, q, a1);
+    }
+    if (i < n)
+    {
+        const double p = x[i];
+        a0             = __builtin_fma(p, p, a0);
+    }
+    const double s = block_sum(a0 + a1, red);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -380,6 +433,54 @@ int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
     return e == hipSuccess ? SF_OK : (int)e;
+}
+
+int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s)
+{
+    Workspace *ws = nullptr;
+    int rc        = workspace(&ws);
+    if (rc != SF_OK)
+        return rc;
+    uint64_t blocks = (n + (uint64_t)kRedThreads * 16 - 1) / ((uint64_t)kRedThreads * 16);
+    if (blocks < 1)
+        blocks = 1;
+    if (blocks > kRedMaxBlock)
+        blocks = kRedMaxBlock;
+    sumsq_partial_f32_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
+    sumsq_final_kernel<<<1, kRedThreads, 0, s>>>(ws->part, (int)blocks, ws->result);
+    rc = launch_rc();
+    if (rc != SF_OK)
+        return rc;
+    hipError_t e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+int fill_sincos_f32(float *in, size_t nelmt, size_t nm_tot, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)nelmt * nm_tot;
+    if (total == 0)
+        return SF_OK;
+    fill_sincos_f32_kernel<<<fill_grid(total), 256, 0, s>>>(in, total, (uint32_t)nm_tot);
+    return launch_rc();
+}
+
+int fill_basis_f32(float *b, size_t nm, size_t nq, hipStream_t s)
+{
+    const uint32_t n = (uint32_t)(nm * nq);
+    if (n == 0)
+        return SF_OK;
+    fill_basis_f32_kernel<<<(n + 255) / 256, 256, 0, s>>>(b, n);
+    return launch_rc();
+}
+
+int fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s)
+{
+    if (n == 0)
+        return SF_OK;
+    fill_random_f32_kernel<<<fill_grid(n), 256, 0, s>>>(x, n, seed, first);
+    return launch_rc();
 }
 
 int fill_sincos(double *in, size_t nelmt, size_t nm_tot, hipStream_t s)

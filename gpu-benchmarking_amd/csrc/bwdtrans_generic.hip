@@ -18,18 +18,19 @@ namespace sf
 {
 
 // ------------------------------------------------------------------------------------------------
-template <bool GLOBAL_WSP>
+template <bool GLOBAL_WSP, typename T>
 __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
-                                                        HexArgs a)
+                                                        HexArgsT<T> a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
     const unsigned nmt = nm0 * nm1 * nm2, nqt = nq0 * nq1 * nq2;
     const unsigned n1 = nq0 * nm1 * nm2, n2 = nq0 * nq1 * nm2;
-    double *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
-    double *sin_ = sb2 + nm2 * nq2;
-    double *sw1  = sin_ + nmt;
-    double *sw2  = sw1 + n1;
+    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
+    T *sin_ = sb2 + nm2 * nq2;
+    T *sw1  = sin_ + nmt;
+    T *sw2  = sw1 + n1;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
 
     for (unsigned x = tid; x < nm0 * nq0; x += nt)
@@ -41,11 +42,11 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
 
     for (uint64_t e = blockIdx.x; e < a.nelmt; e += gridDim.x)
     {
-        const double *ine = a.in + e * nmt;
-        double *oute      = a.out + e * nqt;
-        double *w1        = GLOBAL_WSP ? a.wsp + e * (uint64_t)(n1 + n2) : sw1;
-        double *w2        = GLOBAL_WSP ? w1 + n1 : sw2;
-        const double *src = ine;
+        const T *ine = a.in + e * nmt;
+        T *oute      = a.out + e * nqt;
+        T *w1        = GLOBAL_WSP ? a.wsp + e * (uint64_t)(n1 + n2) : sw1;
+        T *w2        = GLOBAL_WSP ? w1 + n1 : sw2;
+        const T *src = ine;
         if (!GLOBAL_WSP)
         {
             for (unsigned x = tid; x < nmt; x += nt)
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
         for (unsigned x = tid; x < n1; x += nt) // x = (i, r, q)
         {
             const unsigned q = x % nm1, ir = x / nm1, r = ir % nm2, i = ir / nm2;
-            const double *u = src + (r * nm1 + q) * nm0;
-            double t        = 0.0;
+            const T *u = src + (r * nm1 + q) * nm0;
+            T t        = 0;
             for (unsigned p = 0; p < nm0; ++p)
                 t += u[p] * sb0[p * nq0 + i];
             w1[x] = t;
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
         for (unsigned x = tid; x < n2; x += nt) // x = (j, i, r)
         {
             const unsigned r = x % nm2, ji = x / nm2, i = ji % nq0, j = ji / nq0;
-            const double *u = w1 + (i * nm2 + r) * nm1;
-            double t        = 0.0;
+            const T *u = w1 + (i * nm2 + r) * nm1;
+            T t        = 0;
             for (unsigned q = 0; q < nm1; ++q)
                 t += u[q] * sb1[q * nq1 + j];
             w2[x] = t;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
         for (unsigned x = tid; x < nqt; x += nt) // x = (k, j, i)
         {
             const unsigned ji = x % (nq0 * nq1), k = x / (nq0 * nq1);
-            const double *u = w2 + ji * nm2;
-            double t        = 0.0;
+            const T *u = w2 + ji * nm2;
+            T t        = 0;
             for (unsigned r = 0; r < nm2; ++r)
                 t += u[r] * sb2[r * nq2 + k];
             oute[x] = t;
@@ -86,13 +87,15 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(128) void hex_thread_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
-                                                         HexArgs a)
+                                                         HexArgsT<T> a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
     const unsigned nmt = nm0 * nm1 * nm2, nqt = nq0 * nq1 * nq2;
-    double *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
+    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
     for (unsigned x = threadIdx.x; x < nm0 * nq0; x += blockDim.x)
         sb0[x] = a.b0[x];
     for (unsigned x = threadIdx.x; x < nm1 * nq1; x += blockDim.x)
@@ -103,15 +106,15 @@ __global__ __launch_bounds__(128) void hex_thread_kernel(unsigned nq0, unsigned 
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nelmt; e += stride)
     {
-        const double *ine = a.in + e * nmt;
-        double *oute      = a.out + e * nqt;
-        double *s0        = a.wsp + e * (uint64_t)(nm1 * nm2 + nm2); // per-thread scratch
-        double *s1        = s0 + nm1 * nm2;
+        const T *ine = a.in + e * nmt;
+        T *oute      = a.out + e * nqt;
+        T *s0        = a.wsp + e * (uint64_t)(nm1 * nm2 + nm2); // per-thread scratch
+        T *s1        = s0 + nm1 * nm2;
         for (unsigned i = 0; i < nq0; ++i)
         {
             for (unsigned rq = 0; rq < nm1 * nm2; ++rq)
             {
-                double t = 0.0;
+                T t = 0;
                 for (unsigned p = 0; p < nm0; ++p)
                     t += ine[rq * nm0 + p] * sb0[p * nq0 + i];
                 s0[rq] = t;
@@ -120,14 +123,14 @@ __global__ __launch_bounds__(128) void hex_thread_kernel(unsigned nq0, unsigned 
             {
                 for (unsigned r = 0; r < nm2; ++r)
                 {
-                    double t = 0.0;
+                    T t = 0;
                     for (unsigned q = 0; q < nm1; ++q)
                         t += s0[r * nm1 + q] * sb1[q * nq1 + j];
                     s1[r] = t;
                 }
                 for (unsigned k = 0; k < nq2; ++k)
                 {
-                    double t = 0.0;
+                    T t = 0;
                     for (unsigned r = 0; r < nm2; ++r)
                         t += s1[r] * sb2[r * nq2 + k];
                     oute[(k * nq1 + j) * nq0 + i] = t;
@@ -138,15 +141,16 @@ __global__ __launch_bounds__(128) void hex_thread_kernel(unsigned nq0, unsigned 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool GLOBAL_WSP>
-__global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned nq1, QuadArgs a)
+template <bool GLOBAL_WSP, typename T>
+__global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1;
     const unsigned nmt = nm0 * nm1, nqt = nq0 * nq1, n1 = nq0 * nm1;
-    double *sb0 = lds, *sb1 = sb0 + nm0 * nq0;
-    double *sin_ = sb1 + nm1 * nq1;
-    double *sw   = sin_ + nmt;
+    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0;
+    T *sin_ = sb1 + nm1 * nq1;
+    T *sw   = sin_ + nmt;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
     for (unsigned x = tid; x < nm0 * nq0; x += nt)
         sb0[x] = a.b0[x];
@@ -154,10 +158,10 @@ __global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned 
         sb1[x] = a.b1[x];
     for (uint64_t e = blockIdx.x; e < a.nelmt; e += gridDim.x)
     {
-        const double *ine = a.in + e * nmt;
-        double *oute      = a.out + e * nqt;
-        double *w         = GLOBAL_WSP ? a.wsp + e * (uint64_t)n1 : sw;
-        const double *src = ine;
+        const T *ine = a.in + e * nmt;
+        T *oute      = a.out + e * nqt;
+        T *w         = GLOBAL_WSP ? a.wsp + e * (uint64_t)n1 : sw;
+        const T *src = ine;
         if (!GLOBAL_WSP)
         {
             for (unsigned x = tid; x < nmt; x += nt)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned 
         for (unsigned x = tid; x < n1; x += nt) // x = (i, q)
         {
             const unsigned q = x % nm1, i = x / nm1;
-            double t         = 0.0;
+            T t         = 0;
             for (unsigned p = 0; p < nm0; ++p)
                 t += src[q * nm0 + p] * sb0[p * nq0 + i];
             w[x] = t;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned 
         for (unsigned x = tid; x < nqt; x += nt) // x = (j, i)
         {
             const unsigned i = x % nq0, j = x / nq0;
-            double t         = 0.0;
+            T t         = 0;
             for (unsigned q = 0; q < nm1; ++q)
                 t += w[i * nm1 + q] * sb1[q * nq1 + j];
             oute[x] = t;
@@ -186,12 +190,14 @@ __global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned 
     }
 }
 
-__global__ __launch_bounds__(128) void quad_thread_kernel(unsigned nq0, unsigned nq1, QuadArgs a)
+template <typename T>
+__global__ __launch_bounds__(128) void quad_thread_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1;
     const unsigned nmt = nm0 * nm1, nqt = nq0 * nq1;
-    double *sb0 = lds, *sb1 = sb0 + nm0 * nq0;
+    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0;
     for (unsigned x = threadIdx.x; x < nm0 * nq0; x += blockDim.x)
         sb0[x] = a.b0[x];
     for (unsigned x = threadIdx.x; x < nm1 * nq1; x += blockDim.x)
@@ -200,21 +206,21 @@ __global__ __launch_bounds__(128) void quad_thread_kernel(unsigned nq0, unsigned
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nelmt; e += stride)
     {
-        const double *ine = a.in + e * nmt;
-        double *oute      = a.out + e * nqt;
-        double *s         = a.wsp + e * (uint64_t)nm1;
+        const T *ine = a.in + e * nmt;
+        T *oute      = a.out + e * nqt;
+        T *s         = a.wsp + e * (uint64_t)nm1;
         for (unsigned i = 0; i < nq0; ++i)
         {
             for (unsigned q = 0; q < nm1; ++q)
             {
-                double t = 0.0;
+                T t = 0;
                 for (unsigned p = 0; p < nm0; ++p)
                     t += ine[q * nm0 + p] * sb0[p * nq0 + i];
                 s[q] = t;
             }
             for (unsigned j = 0; j < nq1; ++j)
             {
-                double t = 0.0;
+                T t = 0;
                 for (unsigned q = 0; q < nm1; ++q)
                     t += s[q] * sb1[q * nq1 + j];
                 oute[j * nq0 + i] = t;
@@ -232,8 +238,9 @@ static inline int launch_rc()
 
 constexpr size_t kMaxDynLds = 160 * 1024;
 
-int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
-                       hipStream_t s)
+template <typename T>
+int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgsT<T> &a,
+                         hipStream_t s)
 {
     const size_t nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
     const size_t nbas = nm0 * nq0 + nm1 * nq1 + nm2 * nq2;
@@ -242,20 +249,20 @@ int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, co
     {
         if (!a.wsp)
             return SF_EINVAL;
-        const size_t lds = sizeof(double) * nbas;
+        const size_t lds = sizeof(T) * nbas;
         if (lds > kMaxDynLds)
             return SF_ENOTBUILT;
         const uint64_t blocks = (a.nelmt + 127) / 128;
-        hex_thread_kernel<<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
+        hex_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
             nq0, nq1, nq2, a);
         return launch_rc();
     }
     const bool glb = (variant == SF_VARIANT_BLOCK_GLB);
     if (glb && !a.wsp)
         return SF_EINVAL;
-    size_t lds = sizeof(double) * nbas;
+    size_t lds = sizeof(T) * nbas;
     if (!glb)
-        lds += sizeof(double) * (nm0 * nm1 * nm2 + nq0 * nm1 * nm2 + nq0 * nq1 * nm2);
+        lds += sizeof(T) * (nm0 * nm1 * nm2 + nq0 * nm1 * nm2 + nq0 * nq1 * nm2);
     if (lds > kMaxDynLds)
         return SF_ENOTBUILT;
     const unsigned nqt   = nq0 * nq1 * nq2;
@@ -264,20 +271,21 @@ int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, co
     const unsigned grid  = (unsigned)(a.nelmt < cap ? a.nelmt : cap);
     if (glb)
     {
-        (void)hipFuncSetAttribute((const void *)hex_block_kernel<true>,
+        (void)hipFuncSetAttribute((const void *)hex_block_kernel<true, T>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hex_block_kernel<true><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
+        hex_block_kernel<true, T><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
     }
     else
     {
-        (void)hipFuncSetAttribute((const void *)hex_block_kernel<false>,
+        (void)hipFuncSetAttribute((const void *)hex_block_kernel<false, T>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hex_block_kernel<false><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
+        hex_block_kernel<false, T><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
     }
     return launch_rc();
 }
 
-int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s)
+template <typename T>
+int launch_quad_generic_t(int variant, unsigned nq0, unsigned nq1, const QuadArgsT<T> &a, hipStream_t s)
 {
     const size_t nm0 = nq0 - 1, nm1 = nq1 - 1;
     const size_t nbas = nm0 * nq0 + nm1 * nq1;
@@ -286,20 +294,20 @@ int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs 
     {
         if (!a.wsp)
             return SF_EINVAL;
-        const size_t lds = sizeof(double) * nbas;
+        const size_t lds = sizeof(T) * nbas;
         if (lds > kMaxDynLds)
             return SF_ENOTBUILT;
         const uint64_t blocks = (a.nelmt + 127) / 128;
-        quad_thread_kernel<<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
+        quad_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
             nq0, nq1, a);
         return launch_rc();
     }
     const bool glb = (variant == SF_VARIANT_BLOCK_GLB);
     if (glb && !a.wsp)
         return SF_EINVAL;
-    size_t lds = sizeof(double) * nbas;
+    size_t lds = sizeof(T) * nbas;
     if (!glb)
-        lds += sizeof(double) * (nm0 * nm1 + nq0 * nm1);
+        lds += sizeof(T) * (nm0 * nm1 + nq0 * nm1);
     if (lds > kMaxDynLds)
         return SF_ENOTBUILT;
     const unsigned nqt  = nq0 * nq1;
@@ -308,17 +316,37 @@ int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs 
     const unsigned grid = (unsigned)(a.nelmt < cap ? a.nelmt : cap);
     if (glb)
     {
-        (void)hipFuncSetAttribute((const void *)quad_block_kernel<true>,
+        (void)hipFuncSetAttribute((const void *)quad_block_kernel<true, T>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        quad_block_kernel<true><<<grid, thr, lds, s>>>(nq0, nq1, a);
+        quad_block_kernel<true, T><<<grid, thr, lds, s>>>(nq0, nq1, a);
     }
     else
     {
-        (void)hipFuncSetAttribute((const void *)quad_block_kernel<false>,
+        (void)hipFuncSetAttribute((const void *)quad_block_kernel<false, T>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        quad_block_kernel<false><<<grid, thr, lds, s>>>(nq0, nq1, a);
+        quad_block_kernel<false, T><<<grid, thr, lds, s>>>(nq0, nq1, a);
     }
     return launch_rc();
+}
+
+int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
+                       hipStream_t s)
+{
+    return launch_hex_generic_t<double>(variant, nq0, nq1, nq2, a, s);
+}
+int launch_hex_generic_f32(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
+                           const HexArgsT<float> &a, hipStream_t s)
+{
+    return launch_hex_generic_t<float>(variant, nq0, nq1, nq2, a, s);
+}
+int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s)
+{
+    return launch_quad_generic_t<double>(variant, nq0, nq1, a, s);
+}
+int launch_quad_generic_f32(int variant, unsigned nq0, unsigned nq1, const QuadArgsT<float> &a,
+                            hipStream_t s)
+{
+    return launch_quad_generic_t<float>(variant, nq0, nq1, a, s);
 }
 
 } // namespace sf

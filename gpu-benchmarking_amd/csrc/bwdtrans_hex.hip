@@ -51,4 +51,29 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     }
 }
 
+// fp32 (T = float): same kernels with float4 lanes.  Chunks hold twice the fp64 element count (same
+// bytes), always the LDS-staged flat output (the DPP pair store is the fp64 path).
+template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)
+{
+    using C = HexCfg<NQ>;
+    return launch_hex_wave<NQ, 2 * C::EC, C::WPB, C::BM, C::MW, C::KM, OUT_LDS, 0, float>(a, s);
+}
+
+int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s)
+{
+    switch (nq)
+    {
+    case 2: return go_f32<2>(a, s);
+    case 3: return go_f32<3>(a, s);
+    case 4: return go_f32<4>(a, s);
+    case 5: return go_f32<5>(a, s);
+    case 6: return go_f32<6>(a, s);
+    case 7: return go_f32<7>(a, s);
+    case 8: return go_f32<8>(a, s);
+    case 9: return go_f32<9>(a, s);
+    case 10: return go_f32<10>(a, s);
+    default: return SF_ENOTBUILT;
+    }
+}
+
 } // namespace sf

@@ -37,6 +37,26 @@ template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 
+template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
+{
+    using C = QuadCfg<NQ>;
+    return launch_quad_wave<NQ, 2 * C::EC, C::WPB, C::BM, C::MW, C::KM, OUT_LDS, 0, float>(a, s);
+}
+
+// fp32 (T = float): the vector-ALU kernel for every built order (no fp32 matrix-core variant)
+int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s)
+{
+    switch (nq)
+    {
+#define SF_CASE(N) case N: return go_f32<N>(a, s);
+        SF_CASE(2) SF_CASE(3) SF_CASE(4) SF_CASE(5) SF_CASE(6) SF_CASE(7) SF_CASE(8) SF_CASE(9)
+        SF_CASE(10) SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16)
+        SF_CASE(32)
+#undef SF_CASE
+    default: return SF_ENOTBUILT;
+    }
+}
+
 // matrix-core kernel (bwdtrans_mfma.h): every order 11..32; chunks of 2 elements
 template <int NQ> static int go_mfma(const QuadArgs &a, hipStream_t s)
 {

@@ -27,7 +27,10 @@
 //  * Chunk -> wave mapping (template KMAP): 0 = persistent, wave w takes chunks w, w+W, ...;
 //    K > 0 = short-lived waves, wave w takes the K consecutive chunks [wK, wK+K).
 //
-// Algorithmic HBM traffic per element: 8*(nm^d + nq^d) bytes (in read once, out written once).
+//  * Scalar type: every kernel is a template on T (double = the reference's only instantiation; float =
+//    the T the reference's templates allow but never instantiate).  "16-byte lane" = double2 or float4.
+//
+// Algorithmic HBM traffic per element: sizeof(T)*(nm^d + nq^d) bytes (in read once, out written once).
 #pragma once
 
 #include "sf_common.h"
@@ -38,8 +41,8 @@ namespace sf
 // How the last sweep's results reach HBM.
 enum OutMode
 {
-    OUT_ST8  = 0, // straight from registers, 8 B per lane (any nq)
-    OUT_ST16 = 1, // straight from registers, lane pairs swap through DPP -> 16 B per lane (even nq)
+    OUT_ST8  = 0, // straight from registers, one scalar per lane (any nq)
+    OUT_ST16 = 1, // straight from registers, lane pairs swap through DPP -> 16 B per lane (even nq, fp64)
     OUT_LDS  = 2  // through the LDS slab in final layout, then one flat 16-B-per-lane stream (any nq)
 };
 
@@ -48,6 +51,13 @@ enum BasisMode
 {
     BASIS_LDS = 0, // broadcast ds_read from the workgroup's LDS copy
     BASIS_SMEM = 1 // scalar loads (s_load) from global memory -> SGPR operand
+};
+
+// the 16-byte lane of a scalar type
+template <typename T> struct VecOf
+{
+    static constexpr int W = 16 / (int)sizeof(T);
+    typedef T type __attribute__((ext_vector_type(W)));
 };
 
 // exchange a double with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
@@ -59,16 +69,19 @@ __device__ __forceinline__ double swap_adjacent(double v)
     return __hiloint2double(hi, lo);
 }
 
-template <int NQ, int EC, int DIM> struct WaveGeom
+template <int NQ, int EC, int DIM, typename T = double> struct WaveGeom
 {
+    using Scalar = T;
+    using Vec    = typename VecOf<T>::type;
+    static constexpr int VW  = VecOf<T>::W; // scalars per 16-byte lane
     static constexpr int NM  = NQ - 1;
-    static constexpr int NMP = NM | 1; // padded pencil stride (odd number of doubles)
+    static constexpr int NMP = NM | 1; // padded pencil stride (odd number of scalars)
     static constexpr int NMT = (DIM == 3) ? NM * NM * NM : NM * NM; // modes per element
     static constexpr int NQT = (DIM == 3) ? NQ * NQ * NQ : NQ * NQ; // points per element
     // input pencils keep the global layout when NM is odd (already conflict-free)
     static constexpr int IN_STRIDE = (NM % 2 == 0) ? NM + 1 : NM;
-    static constexpr int IN_DBL    = EC * NMT;     // doubles per chunk in HBM
-    static constexpr bool VEC2     = (IN_DBL % 2) == 0;
+    static constexpr int IN_DBL    = EC * NMT; // scalars per chunk in HBM
+    static constexpr bool VEC2     = (IN_DBL % VW) == 0; // chunk is a whole number of 16-B lanes
     // pencils per chunk in each sweep
     static constexpr int P0 = (DIM == 3) ? EC * NM * NM : EC * NM; // (e,r,q) | (e,q)
     static constexpr int P1 = (DIM == 3) ? EC * NQ * NM : EC * NQ; // (e,i,r) | (e,i)
@@ -76,28 +89,29 @@ template <int NQ, int EC, int DIM> struct WaveGeom
     static constexpr int PASS0 = cdiv(P0, kWave);
     static constexpr int PASS1 = cdiv(P1, kWave);
     static constexpr int PASS2 = cdiv(P2, kWave);
-    // LDS slab per wave (doubles): max over the three images that live in it, one after another
+    // LDS slab per wave (scalars): max over the three images that live in it, one after another
     static constexpr int SLAB_IN = P0 * IN_STRIDE;
     static constexpr int SLAB_W1 = P1 * NMP;
     static constexpr int SLAB_W2 = (DIM == 3) ? P2 * NMP : 0;
     static constexpr int SLAB0   = CMax<CMax<SLAB_IN, SLAB_W1>::value, SLAB_W2>::value;
-    static constexpr int OUT_DBL = EC * NQT;          // doubles per chunk written to HBM
+    static constexpr int OUT_DBL = EC * NQT; // scalars per chunk written to HBM
     // slab without / with room for the output image (OUT_LDS), kept 16-B aligned
-    static constexpr int SLAB_NOOUT = (SLAB0 + 1) & ~1;
-    static constexpr int SLAB_OUT   = (CMax<SLAB0, OUT_DBL>::value + 1) & ~1;
-    static constexpr int NBAS    = (NM * NQ + 1) & ~1;
-    static constexpr int NLD     = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
+    static constexpr int SLAB_NOOUT = (SLAB0 + VW - 1) / VW * VW;
+    static constexpr int SLAB_OUT   = (CMax<SLAB0, OUT_DBL>::value + VW - 1) / VW * VW;
+    static constexpr int NBAS = (NM * NQ + VW - 1) / VW * VW;
+    static constexpr int NLD  = VEC2 ? cdiv(IN_DBL / VW, kWave) : cdiv(IN_DBL, kWave);
 };
 
 template <class G, int OUTM> constexpr int slab_doubles()
 {
-    return OUTM == 2 ? G::SLAB_OUT : G::SLAB_NOOUT;
+    return OUTM == OUT_LDS ? G::SLAB_OUT : G::SLAB_NOOUT;
 }
 
-template <int NQ, int EC, int DIM, int WPB, int BMODE, int OUTM> constexpr size_t wave_lds_bytes()
+template <int NQ, int EC, int DIM, int WPB, int BMODE, int OUTM, typename T = double>
+constexpr size_t wave_lds_bytes()
 {
-    using G = WaveGeom<NQ, EC, DIM>;
-    return sizeof(double) *
+    using G = WaveGeom<NQ, EC, DIM, T>;
+    return sizeof(T) *
            (size_t)((BMODE == BASIS_LDS ? DIM * G::NBAS : 0) + WPB * slab_doubles<G, OUTM>());
 }
 
@@ -132,28 +146,37 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
 // chunk load: global -> staging registers (issued one chunk ahead of its use)
 // ------------------------------------------------------------------------------------------------
 template <class G, bool FULL, bool NTL = true>
-__device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double *__restrict__ src,
-                                           int lane, int nvalid /*doubles, only if !FULL*/)
+__device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
+                                           const typename G::Scalar *__restrict__ src, int lane,
+                                           int nvalid /*scalars, only if !FULL*/)
 {
+    using T = typename G::Scalar;
+    using V = typename G::Vec;
+    constexpr int VW = G::VW;
     if constexpr (G::VEC2)
     {
-        const double2_t *src2 = reinterpret_cast<const double2_t *>(src);
+        const V *srcv = reinterpret_cast<const V *>(src);
 #pragma unroll
         for (int k = 0; k < G::NLD; ++k)
         {
             const int v = k * kWave + lane;
             if constexpr (FULL)
             {
-                if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
-                    st[k] = NTL ? __builtin_nontemporal_load(src2 + v) : src2[v];
+                if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
+                    st[k] = NTL ? __builtin_nontemporal_load(srcv + v) : srcv[v];
             }
             else
             {
-                double2_t x = {0.0, 0.0};
-                if (2 * v + 1 < nvalid)
-                    x = NTL ? __builtin_nontemporal_load(src2 + v) : src2[v];
-                else if (2 * v < nvalid)
-                    x.x = NTL ? __builtin_nontemporal_load(src + 2 * v) : src[2 * v];
+                V x = {};
+                if (VW * v + VW - 1 < nvalid)
+                    x = NTL ? __builtin_nontemporal_load(srcv + v) : srcv[v];
+                else
+                {
+#pragma unroll
+                    for (int j = 0; j < VW - 1; ++j) // ragged tail of the last partial chunk
+                        if (VW * v + j < nvalid)
+                            x[j] = src[VW * v + j];
+                }
                 st[k] = x;
             }
         }
@@ -164,35 +187,41 @@ __device__ __forceinline__ void chunk_load(double2_t (&st)[G::NLD], const double
         for (int k = 0; k < G::NLD; ++k)
         {
             const int v = k * kWave + lane;
-            double x    = 0.0;
+            T x         = 0;
             if (v < (FULL ? G::IN_DBL : nvalid))
                 x = NTL ? __builtin_nontemporal_load(src + v) : src[v];
-            st[k].x = x;
+            st[k][0] = x;
         }
     }
 }
 
 // staging registers -> LDS slab, pencil stride IN_STRIDE
 template <class G>
-__device__ __forceinline__ void chunk_stage(const double2_t (&st)[G::NLD], double *slab, int lane)
+__device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
+                                            typename G::Scalar *slab, int lane)
 {
+    using V = typename G::Vec;
+    constexpr int VW = G::VW;
     if constexpr (G::VEC2)
     {
 #pragma unroll
         for (int k = 0; k < G::NLD; ++k)
         {
             const int v = k * kWave + lane;
-            if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+            if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
             {
                 if constexpr (G::IN_STRIDE == G::NM)
                 {
-                    *reinterpret_cast<double2_t *>(slab + 2 * v) = st[k];
+                    *reinterpret_cast<V *>(slab + VW * v) = st[k];
                 }
                 else
                 {
-                    const int f0 = 2 * v, f1 = 2 * v + 1;
-                    slab[f0 + f0 / G::NM] = st[k].x;
-                    slab[f1 + f1 / G::NM] = st[k].y;
+#pragma unroll
+                    for (int j = 0; j < VW; ++j)
+                    {
+                        const int f          = VW * v + j;
+                        slab[f + f / G::NM] = st[k][j];
+                    }
                 }
             }
         }
@@ -206,9 +235,9 @@ __device__ __forceinline__ void chunk_stage(const double2_t (&st)[G::NLD], doubl
             if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
             {
                 if constexpr (G::IN_STRIDE == G::NM)
-                    slab[v] = st[k].x;
+                    slab[v] = st[k][0];
                 else
-                    slab[v + v / G::NM] = st[k].x;
+                    slab[v + v / G::NM] = st[k][0];
             }
         }
     }
@@ -217,27 +246,20 @@ __device__ __forceinline__ void chunk_stage(const double2_t (&st)[G::NLD], doubl
 // ------------------------------------------------------------------------------------------------
 // one contraction: acc[pass][n] = sum_m u[pass][m] * B[m*NOUT + n], ascending m, start at 0
 // ------------------------------------------------------------------------------------------------
-template <int NIN, int NOUT, int NPASS, int BMODE>
-__device__ __forceinline__ void contract(const double (&u)[NPASS][NIN], double (&acc)[NPASS][NOUT],
-                                         const double *__restrict__ bas)
+template <int NIN, int NOUT, int NPASS, int BMODE, typename T>
+__device__ __forceinline__ void contract(const T (&u)[NPASS][NIN], T (&acc)[NPASS][NOUT],
+                                         const T *__restrict__ bas)
 {
     // The basis is consumed one ROW (fixed m, all n) at a time, with the next row's operands
-    // requested before the current row's FMAs and a scheduling fence after them: left alone, hipcc
+    // requested before the current row's FMAs and an order fence after them: left alone, hipcc
     // hoists every basis load of the sweep (and of later sweeps) to the top and then spills.
+    // The offset is opaque (not the pointer: the pointer must stay a provably global, unclobbered
+    // kernel argument to get s_load) so the loads also stay inside the chunk loop.
     int zero = 0;
-    if constexpr (BMODE == BASIS_SMEM)
-    {
-        // keep the scalar loads inside the chunk loop (an opaque OFFSET, not an opaque pointer: the
-        // pointer must stay a provably global, unclobbered kernel argument to get s_load)
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    }
-    else
-    {
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    }
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     // ring of operand rows: scalar loads come from the K-cache / L2 (longer latency) -> 2 rows ahead
     constexpr int PFD = (BMODE == BASIS_SMEM) ? 2 : 1, RING = PFD + 1;
-    double b[RING][NOUT];
+    T b[RING][NOUT];
 #pragma unroll
     for (int r = 0; r < PFD && r < NIN; ++r)
 #pragma unroll
@@ -271,8 +293,8 @@ __device__ __forceinline__ void contract(const double (&u)[NPASS][NIN], double (
 }
 
 // read the pencils of this lane: u[pass][m] = slab[t*STRIDE + m], t = pass*64 + lane < NP
-template <int NIN, int NPASS, int NP, int STRIDE>
-__device__ __forceinline__ void read_pencils(double (&u)[NPASS][NIN], const double *slab, int lane)
+template <int NIN, int NPASS, int NP, int STRIDE, typename T>
+__device__ __forceinline__ void read_pencils(T (&u)[NPASS][NIN], const T *slab, int lane)
 {
 #pragma unroll
     for (int s = 0; s < NPASS; ++s)
@@ -289,9 +311,8 @@ __device__ __forceinline__ void read_pencils(double (&u)[NPASS][NIN], const doub
 // ------------------------------------------------------------------------------------------------
 // shared prologue: basis pointers (LDS copy or the global arrays themselves) and the wave's slab
 // ------------------------------------------------------------------------------------------------
-template <class G, int DIM, int WPB, int BMODE, int SLAB>
-__device__ __forceinline__ double *wave_setup(double *lds, const double *const (&gb)[3],
-                                              const double *(&bs)[3], int wib)
+template <class G, int DIM, int WPB, int BMODE, int SLAB, typename T>
+__device__ __forceinline__ T *wave_setup(T *lds, const T *const (&gb)[3], const T *(&bs)[3], int wib)
 {
     if constexpr (BMODE == BASIS_LDS)
     {
@@ -315,8 +336,9 @@ __device__ __forceinline__ double *wave_setup(double *lds, const double *const (
 }
 
 template <class G, int EC, bool NTL = true>
-__device__ __forceinline__ void chunk_fetch(double2_t (&st)[G::NLD], const double *__restrict__ in,
-                                            uint64_t c, uint64_t nelmt, int lane)
+__device__ __forceinline__ void chunk_fetch(typename G::Vec (&st)[G::NLD],
+                                            const typename G::Scalar *__restrict__ in, uint64_t c,
+                                            uint64_t nelmt, int lane)
 {
     const uint64_t left = nelmt - c * EC;
     if (left >= EC)
@@ -326,12 +348,13 @@ __device__ __forceinline__ void chunk_fetch(double2_t (&st)[G::NLD], const doubl
 }
 
 // Final-sweep store of one pass: lane t owns NOUT values acc[n] destined for dst[n*NSTRIDE]
-// (consecutive lanes -> consecutive doubles).  ST16: lane pairs exchange so each lane stores 16 B.
-template <int NOUT, int NSTRIDE, bool ST16, bool NTS = true>
-__device__ __forceinline__ void store_column(const double (&acc)[NOUT], double *dst, int lane)
+// (consecutive lanes -> consecutive scalars).  ST16 (fp64): lane pairs exchange so each lane stores 16 B.
+template <int NOUT, int NSTRIDE, bool ST16, bool NTS = true, typename T>
+__device__ __forceinline__ void store_column(const T (&acc)[NOUT], T *dst, int lane)
 {
     if constexpr (ST16)
     {
+        static_assert(sizeof(T) == 8, "paired 16-byte stores are the fp64 path");
         static_assert(NOUT % 2 == 0 && NSTRIDE % 2 == 0, "16-byte stores need even extents");
         const bool odd = lane & 1;
         double *d2     = dst - (odd ? 1 : 0) + (odd ? NSTRIDE : 0);
@@ -362,30 +385,37 @@ __device__ __forceinline__ void store_column(const double (&acc)[NOUT], double *
     }
 }
 
-// OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` doubles to HBM
-// with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is even; else 8-B lanes).
+// OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` scalars to HBM
+// with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is a multiple of VW; else scalar lanes).
 template <class G, bool NTS>
-__device__ __forceinline__ void chunk_flush(const double *slab, double *__restrict__ dst, int nout,
-                                            int lane)
+__device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
+                                            typename G::Scalar *__restrict__ dst, int nout, int lane)
 {
-    if constexpr (G::OUT_DBL % 2 == 0)
+    using V = typename G::Vec;
+    constexpr int VW = G::VW;
+    if constexpr (G::OUT_DBL % VW == 0)
     {
-        constexpr int NST = cdiv(G::OUT_DBL / 2, kWave);
-        double2_t *dst2   = reinterpret_cast<double2_t *>(dst);
+        constexpr int NST = cdiv(G::OUT_DBL / VW, kWave);
+        V *dstv           = reinterpret_cast<V *>(dst);
 #pragma unroll
         for (int k = 0; k < NST; ++k)
         {
             const int v = k * kWave + lane;
-            if (2 * v + 1 < nout)
+            if (VW * v + VW - 1 < nout)
             {
-                const double2_t x = *reinterpret_cast<const double2_t *>(slab + 2 * v);
+                const V x = *reinterpret_cast<const V *>(slab + VW * v);
                 if (NTS)
-                    __builtin_nontemporal_store(x, dst2 + v);
+                    __builtin_nontemporal_store(x, dstv + v);
                 else
-                    dst2[v] = x;
+                    dstv[v] = x;
             }
-            else if (2 * v < nout)
-                dst[2 * v] = slab[2 * v];
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < VW - 1; ++j)
+                    if (VW * v + j < nout)
+                        dst[VW * v + j] = slab[VW * v + j];
+            }
         }
     }
     else
@@ -409,29 +439,32 @@ __device__ __forceinline__ void chunk_flush(const double *slab, double *__restri
 // ------------------------------------------------------------------------------------------------
 // 3D hex
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0,
+          typename T = double>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
-    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
-    const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
+    const T *__restrict__ b0, const T *__restrict__ b1, const T *__restrict__ b2,
+    const T *__restrict__ in, T *__restrict__ out, uint64_t nelmt)
 {
-    using G          = WaveGeom<NQ, EC, 3>;
+    using G          = WaveGeom<NQ, EC, 3, T>;
     constexpr int NM = G::NM, NMP = G::NMP, NM2 = NM * NM, NQ2 = NQ * NQ;
-    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0), "paired 16-byte stores need even nq");
+    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0 && sizeof(T) == 8),
+                  "paired 16-byte stores need even nq and fp64");
     constexpr int SLAB = slab_doubles<G, OUTM>();
 
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double *const gb[3] = {b0, b1, b2};
-    const double *bs[3];
-    double *slab = wave_setup<G, 3, WPB, BMODE, SLAB>(lds, gb, bs, wib);
+    const T *const gb[3] = {b0, b1, b2};
+    const T *bs[3];
+    T *slab = wave_setup<G, 3, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
     if (it.count == 0)
         return;
 
-    double2_t st[G::NLD];
+    typename G::Vec st[G::NLD];
     chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
@@ -450,7 +483,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
 
         // ---- direction 0: w1[(e,i,r)][q] = sum_p in[(e,r,q)][p] * B0[p][i] ----------------------
         {
-            double u[G::PASS0][NM], acc[G::PASS0][NQ];
+            T u[G::PASS0][NM], acc[G::PASS0][NQ];
             read_pencils<NM, G::PASS0, G::P0, G::IN_STRIDE>(u, slab, lane);
             contract<NM, NQ, G::PASS0, BMODE>(u, acc, bs[0]);
             wave_lds_fence();
@@ -461,7 +494,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
                 if ((s + 1) * kWave <= G::P0 || t < G::P0)
                 {
                     const int e = t / NM2, rq = t - e * NM2, r = rq / NM, q = rq - r * NM;
-                    double *dst = slab + (e * NQ * NM + r) * NMP + q;
+                    T *dst = slab + (e * NQ * NM + r) * NMP + q;
 #pragma unroll
                     for (int i = 0; i < NQ; ++i)
                         dst[i * NM * NMP] = acc[s][i];
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         }
         // ---- direction 1: w2[(e,j,i)][r] = sum_q w1[(e,i,r)][q] * B1[q][j] ----------------------
         {
-            double u[G::PASS1][NM], acc[G::PASS1][NQ];
+            T u[G::PASS1][NM], acc[G::PASS1][NQ];
             read_pencils<NM, G::PASS1, G::P1, NMP>(u, slab, lane);
             contract<NM, NQ, G::PASS1, BMODE>(u, acc, bs[1]);
             wave_lds_fence();
@@ -483,7 +516,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
                 {
                     const int e = t / (NQ * NM), ir = t - e * (NQ * NM), i = ir / NM,
                               r = ir - i * NM;
-                    double *dst = slab + (e * NQ2 + i) * NMP + r;
+                    T *dst = slab + (e * NQ2 + i) * NMP + r;
 #pragma unroll
                     for (int j = 0; j < NQ; ++j)
                         dst[j * NQ * NMP] = acc[s][j];
@@ -493,10 +526,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         }
         // ---- direction 2: out[e][k][(j,i)] = sum_r w2[(e,j,i)][r] * B2[r][k] --------------------
         {
-            double u[G::PASS2][NM], acc[G::PASS2][NQ];
+            T u[G::PASS2][NM], acc[G::PASS2][NQ];
             read_pencils<NM, G::PASS2, G::P2, NMP>(u, slab, lane);
             contract<NM, NQ, G::PASS2, BMODE>(u, acc, bs[2]);
-            double *oc = out + c * (uint64_t)(EC * G::NQT);
+            T *oc = out + c * (uint64_t)(EC * G::NQT);
             if constexpr (OUTM == OUT_LDS)
             {
                 wave_lds_fence();
@@ -507,7 +540,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
                     if ((s + 1) * kWave <= G::P2 || t < G::P2)
                     {
                         const int e = t / NQ2, pl = t - e * NQ2;
-                        double *dst = slab + e * G::NQT + pl;
+                        T *dst = slab + e * G::NQT + pl;
 #pragma unroll
                         for (int k = 0; k < NQ; ++k)
                             dst[k * NQ2] = acc[s][k];
@@ -536,29 +569,32 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
 // ------------------------------------------------------------------------------------------------
 // 2D quad
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0>
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP, int OUTM, int MEMF = 0,
+          typename T = double>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
-    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
-    double *__restrict__ out, uint64_t nelmt)
+    const T *__restrict__ b0, const T *__restrict__ b1, const T *__restrict__ in,
+    T *__restrict__ out, uint64_t nelmt)
 {
-    using G          = WaveGeom<NQ, EC, 2>;
+    using G          = WaveGeom<NQ, EC, 2, T>;
     constexpr int NM = G::NM, NMP = G::NMP;
-    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0), "paired 16-byte stores need even nq");
+    static_assert(OUTM != OUT_ST16 || (NQ % 2 == 0 && sizeof(T) == 8),
+                  "paired 16-byte stores need even nq and fp64");
     constexpr int SLAB = slab_doubles<G, OUTM>();
 
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double *const gb[3] = {b0, b1, nullptr};
-    const double *bs[3];
-    double *slab = wave_setup<G, 2, WPB, BMODE, SLAB>(lds, gb, bs, wib);
+    const T *const gb[3] = {b0, b1, nullptr};
+    const T *bs[3];
+    T *slab = wave_setup<G, 2, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
     if (it.count == 0)
         return;
 
-    double2_t st[G::NLD];
+    typename G::Vec st[G::NLD];
     chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
@@ -574,7 +610,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
 
         // ---- direction 0: w[(e,i)][q] = sum_p in[(e,q)][p] * B0[p][i] ---------------------------
         {
-            double u[G::PASS0][NM], acc[G::PASS0][NQ];
+            T u[G::PASS0][NM], acc[G::PASS0][NQ];
             read_pencils<NM, G::PASS0, G::P0, G::IN_STRIDE>(u, slab, lane);
             contract<NM, NQ, G::PASS0, BMODE>(u, acc, bs[0]);
             wave_lds_fence();
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
                 if ((s + 1) * kWave <= G::P0 || t < G::P0)
                 {
                     const int e = t / NM, q = t - e * NM;
-                    double *dst = slab + e * NQ * NMP + q;
+                    T *dst = slab + e * NQ * NMP + q;
 #pragma unroll
                     for (int i = 0; i < NQ; ++i)
                         dst[i * NMP] = acc[s][i];
@@ -595,10 +631,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
         }
         // ---- direction 1: out[e][j][i] = sum_q w[(e,i)][q] * B1[q][j] ---------------------------
         {
-            double u[G::PASS1][NM], acc[G::PASS1][NQ];
+            T u[G::PASS1][NM], acc[G::PASS1][NQ];
             read_pencils<NM, G::PASS1, G::P1, NMP>(u, slab, lane);
             contract<NM, NQ, G::PASS1, BMODE>(u, acc, bs[1]);
-            double *oc = out + c * (uint64_t)(EC * G::NQT);
+            T *oc = out + c * (uint64_t)(EC * G::NQT);
             if constexpr (OUTM == OUT_LDS)
             {
                 wave_lds_fence();
@@ -609,7 +645,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
                     if ((s + 1) * kWave <= G::P1 || t < G::P1)
                     {
                         const int e = t / NQ, i = t - e * NQ;
-                        double *dst = slab + e * G::NQT + i;
+                        T *dst = slab + e * G::NQT + i;
 #pragma unroll
                         for (int j = 0; j < NQ; ++j)
                             dst[j * NQ] = acc[s][j];

@@ -27,6 +27,16 @@ int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
 int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
 int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
 int release_workspaces();
+int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s);
+int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s);
+int launch_hex_generic_f32(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
+                           const HexArgsT<float> &a, hipStream_t s);
+int launch_quad_generic_f32(int variant, unsigned nq0, unsigned nq1, const QuadArgsT<float> &a,
+                            hipStream_t s);
+int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s);
+int fill_sincos_f32(float *in, size_t nelmt, size_t nm_tot, hipStream_t s);
+int fill_basis_f32(float *b, size_t nm, size_t nq, hipStream_t s);
+int fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
 } // namespace sf
 
 using namespace sf;
@@ -180,6 +190,86 @@ int sf_bwdtrans_quad_f64(unsigned nq0, unsigned nq1, size_t nelmt, const double 
 {
     return sf_bwdtrans_quad_f64_variant(SF_VARIANT_AUTO, nq0, nq1, nelmt, basis0, basis1, in,
                                         nullptr, out, stream);
+}
+
+// ---- fp32 (T = float) ------------------------------------------------------------------------------
+int sf_bwdtrans_hex_f32(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt, const float *basis0,
+                        const float *basis1, const float *basis2, const float *in, float *out,
+                        void *stream)
+{
+    if (nq0 < 2 || nq1 < 2 || nq2 < 2)
+        return SF_EINVAL;
+    if (nelmt == 0)
+        return SF_OK;
+    if (!basis0 || !basis1 || !basis2 || !in || !out)
+        return SF_EINVAL;
+    if (!aligned(in, 4) || !aligned(out, 4) || !aligned(basis0, 4) || !aligned(basis1, 4) ||
+        !aligned(basis2, 4))
+        return SF_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    HexArgsT<float> a{basis0, basis1, basis2, in, nullptr, out, (uint64_t)nelmt};
+    if (nq0 == nq1 && nq1 == nq2 && aligned(in, 16) && aligned(out, 16))
+    {
+        int rc = launch_hex_wave_f32_nq(nq0, a, s);
+        if (rc != SF_ENOTBUILT)
+            return rc;
+    }
+    return launch_hex_generic_f32(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+}
+
+int sf_bwdtrans_quad_f32(unsigned nq0, unsigned nq1, size_t nelmt, const float *basis0,
+                         const float *basis1, const float *in, float *out, void *stream)
+{
+    if (nq0 < 2 || nq1 < 2)
+        return SF_EINVAL;
+    if (nelmt == 0)
+        return SF_OK;
+    if (!basis0 || !basis1 || !in || !out)
+        return SF_EINVAL;
+    if (!aligned(in, 4) || !aligned(out, 4) || !aligned(basis0, 4) || !aligned(basis1, 4))
+        return SF_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    QuadArgsT<float> a{basis0, basis1, in, nullptr, out, (uint64_t)nelmt};
+    if (nq0 == nq1 && aligned(in, 16) && aligned(out, 16))
+    {
+        int rc = launch_quad_wave_f32_nq(nq0, a, s);
+        if (rc != SF_ENOTBUILT)
+            return rc;
+    }
+    return launch_quad_generic_f32(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+}
+
+int sf_sumsq_f32(const float *x, size_t n, double *result_host, void *stream)
+{
+    if (!result_host || (!x && n))
+        return SF_EINVAL;
+    if (n == 0)
+    {
+        *result_host = 0.0;
+        return SF_OK;
+    }
+    return sumsq_f32_blocking(x, n, result_host, (hipStream_t)stream);
+}
+
+int sf_fill_sincos_f32(float *in, size_t nelmt, size_t nm_tot, void *stream)
+{
+    if ((!in && nelmt * nm_tot) || nm_tot > 0xffffffffull)
+        return SF_EINVAL;
+    return fill_sincos_f32(in, nelmt, nm_tot, (hipStream_t)stream);
+}
+
+int sf_fill_basis_f32(float *basis, size_t nm, size_t nq, void *stream)
+{
+    if ((!basis && nm * nq) || nm * nq > 0xffffffffull)
+        return SF_EINVAL;
+    return fill_basis_f32(basis, nm, nq, (hipStream_t)stream);
+}
+
+int sf_fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first_idx, void *stream)
+{
+    if (!x && n)
+        return SF_EINVAL;
+    return fill_random_f32(x, n, seed, first_idx, (hipStream_t)stream);
 }
 
 int sf_sumsq_f64(const double *x, size_t n, double *result_host, void *stream)

@@ -15,20 +15,23 @@ constexpr int kWave = 64; // CDNA4 wavefront
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// Launch descriptor filled by the per-nq dispatch tables.
-struct HexArgs
+// Launch descriptors filled by the per-nq dispatch tables.
+template <typename T> struct HexArgsT
 {
-    const double *b0, *b1, *b2, *in;
-    double *wsp, *out;
+    const T *b0, *b1, *b2, *in;
+    T *wsp, *out;
     uint64_t nelmt;
 };
 
-struct QuadArgs
+template <typename T> struct QuadArgsT
 {
-    const double *b0, *b1, *in;
-    double *wsp, *out;
+    const T *b0, *b1, *in;
+    T *wsp, *out;
     uint64_t nelmt;
 };
+
+using HexArgs  = HexArgsT<double>;
+using QuadArgs = QuadArgsT<double>;
 
 struct DeviceInfo
 {

@@ -34,12 +34,13 @@ template <class K> inline int resident_blocks(K kern, int threads, size_t lds, i
     return cache[dev] * device_info().num_cu;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0>
-inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 0)
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0,
+          typename T = double>
+inline int launch_hex_wave(const HexArgsT<T> &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE, OUTM>();
+    auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF, T>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE, OUTM, T>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;
@@ -58,12 +59,13 @@ inline int launch_hex_wave(const HexArgs &a, hipStream_t s, int grid_override = 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0>
-inline int launch_quad_wave(const QuadArgs &a, hipStream_t s, int grid_override = 0)
+template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0,
+          typename T = double>
+inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF>;
-    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE, OUTM>();
+    auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF, T>;
+    constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE, OUTM, T>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;

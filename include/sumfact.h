@@ -122,6 +122,21 @@ int sf_fill_l2norm_f64(double *x, size_t n, void *stream);
 int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream);
 
 /*
+ * fp32: the reference's kernels are templates on T but only T = double is ever
+ * instantiated (benchmark05/benchmark05.cc:15, 1439); these are the T = float instantiations of the
+ * same kernels (float4 lanes).  sumsq accumulates in double.  Same layouts and error codes.
+ */
+int sf_bwdtrans_hex_f32(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt, const float *basis0,
+                        const float *basis1, const float *basis2, const float *in, float *out,
+                        void *stream);
+int sf_bwdtrans_quad_f32(unsigned nq0, unsigned nq1, size_t nelmt, const float *basis0,
+                         const float *basis1, const float *in, float *out, void *stream);
+int sf_sumsq_f32(const float *x, size_t n, double *result_host, void *stream);
+int sf_fill_sincos_f32(float *in, size_t nelmt, size_t nm_tot, void *stream);
+int sf_fill_basis_f32(float *basis, size_t nm, size_t nq, void *stream);
+int sf_fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first_idx, void *stream);
+
+/*
  * benchmark02: x[i] += y[i]  -- replaces add_vector<T,vl><<<>>>
  * (benchmark02/benchmark02.cc:16-58); 24 bytes of HBM traffic per element (:255), so its GB/s is the
  * measured stream rate used as the second roofline denominator.  fill: data1/data2 of :84-85.

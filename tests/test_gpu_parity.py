@@ -212,6 +212,46 @@ def test_vecadd_and_matvec(sf, oracle, golden, torch_mod):
     assert oracle.rel_err(_np(sf.matvec(37, 101, a, x)), yo) <= TOL
 
 
+TOL32 = 2e-5   # fp32: eps = 6e-8, sums of up to 3*31 products with cancellation
+
+
+def test_fp32_parity(sf, oracle, golden, torch_mod):
+    """T = float instantiations: the oracle evaluates the same float inputs in fp64."""
+    f32 = torch_mod.float32
+    for nq in list(range(2, 11)) + [(3, 5, 4)]:
+        nqs = (nq,) * 3 if isinstance(nq, int) else nq
+        nm = [q - 1 for q in nqs]
+        for nelmt in (1, 3, 17, 130, 1001):
+            bs = [sf.fill_random(nm[d] * nqs[d], 31 + d, dtype=f32) for d in range(3)]
+            x = sf.fill_random(nelmt * nm[0] * nm[1] * nm[2], nelmt, dtype=f32)
+            out = sf.bwdtrans_hex(nqs, *bs, x)
+            assert out.dtype == f32
+            ref = oracle.bwdtrans_hex(nqs, nelmt, *[_np(b).astype(np.float64) for b in bs],
+                                      _np(x).astype(np.float64))
+            assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nqs, nelmt)
+    for nq in list(range(2, 17)) + [32, (4, 9)]:
+        nqs = (nq, nq) if isinstance(nq, int) else nq
+        nm = [q - 1 for q in nqs]
+        for nelmt in (1, 5, 64, 999):
+            bs = [sf.fill_random(nm[d] * nqs[d], 41 + d, dtype=f32) for d in range(2)]
+            x = sf.fill_random(nelmt * nm[0] * nm[1], nelmt, dtype=f32)
+            out = sf.bwdtrans_quad(nqs, *bs, x)
+            ref = oracle.bwdtrans_quad(nqs, nelmt, *[_np(b).astype(np.float64) for b in bs],
+                                       _np(x).astype(np.float64))
+            assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nqs, nelmt)
+    # fills: the fp64 generator rounded to float; sin/cos in float
+    a = _np(sf.fill_random(10007, 5, 3, dtype=f32))
+    assert np.array_equal(a, oracle.fill_random(10007, 5, 3).astype(np.float32))
+    s = _np(sf.fill_sincos(3, 343, dtype=f32))
+    assert np.max(np.abs(s - np.sin(np.arange(1, 344, dtype=np.float32)).repeat(1)[None, :].repeat(3, 0).ravel())) < 1e-6
+    # golden norm on the reference's data, to fp32 accuracy
+    b = sf.fill_basis(7, 8, dtype=f32)
+    x = sf.fill_sincos(4096, 343, dtype=f32)
+    norm = math.sqrt(sf.sumsq(sf.bwdtrans_hex((8, 8, 8), b, b, b, x)))
+    want = [float(r["norm"]) for r in golden["hex"]["8"]["rows"] if r["n"] == 4096][0]
+    assert abs(norm - want) <= 2e-5 * want
+
+
 def test_empty_and_errors(sf, torch_mod):
     capi = sf.capi
     b = sf.fill_basis(7, 8)
