@@ -14,8 +14,11 @@
 //   5 rocBLAS               1 DGEMM + 2 strided-batched DGEMMs, global wsp (cuBLAS column :1062-1171)
 // `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
-// --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4).
+// --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4), --precision f64|f32
+// (f32 = the T = float instantiation the reference's templates allow: flagship column only).
 #include "harness.h"
+
+#include <type_traits>
 
 using namespace harness;
 
@@ -26,7 +29,7 @@ template <typename T>
 void run_test(const unsigned int size, const unsigned int _nq0, const unsigned int _nq1,
               const unsigned int _nq2, const unsigned int _threads, const unsigned int _elblocks)
 {
-    static_assert(sizeof(T) == sizeof(double), "only T = double is instantiated (as in the reference)");
+    constexpr bool kF32 = std::is_same<T, float>::value; // --precision f32: flagship column only
     (void)_threads;
     (void)_elblocks;
     const size_t nelmt = size;
@@ -36,16 +39,29 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
 
     DeviceBuffer<T> d_in(nelmt * nmTot), d_out(nelmt * nqTot);
     DeviceBuffer<T> d_basis0(nm0 * nq0), d_basis1(nm1 * nq1), d_basis2(nm2 * nq2);
-    DeviceBuffer<T> d_wsp(g_opt.baselines ? nelmt * ((size_t)nq0 * nm1 * nm2 + (size_t)nq0 * nq1 * nm2) : 0);
+    DeviceBuffer<T> d_wsp((g_opt.baselines && !kF32) ? nelmt * ((size_t)nq0 * nm1 * nm2 + (size_t)nq0 * nq1 * nm2) : 0);
 
     // in[e][f] = sin(f+1), basis[x] = cos(x)  (benchmark05.cc:1195-1236), generated on the device
-    if (g_opt.data == "random")
-        SF_CHECK(sf_fill_random_f64(d_in.get(), nelmt * nmTot, g_opt.seed, 0, nullptr));
+    if constexpr (kF32)
+    {
+        if (g_opt.data == "random")
+            SF_CHECK(sf_fill_random_f32(d_in.get(), nelmt * nmTot, g_opt.seed, 0, nullptr));
+        else
+            SF_CHECK(sf_fill_sincos_f32(d_in.get(), nelmt, nmTot, nullptr));
+        SF_CHECK(sf_fill_basis_f32(d_basis0.get(), nm0, nq0, nullptr));
+        SF_CHECK(sf_fill_basis_f32(d_basis1.get(), nm1, nq1, nullptr));
+        SF_CHECK(sf_fill_basis_f32(d_basis2.get(), nm2, nq2, nullptr));
+    }
     else
-        SF_CHECK(sf_fill_sincos_f64(d_in.get(), nelmt, nmTot, nullptr));
-    SF_CHECK(sf_fill_basis_f64(d_basis0.get(), nm0, nq0, nullptr));
-    SF_CHECK(sf_fill_basis_f64(d_basis1.get(), nm1, nq1, nullptr));
-    SF_CHECK(sf_fill_basis_f64(d_basis2.get(), nm2, nq2, nullptr));
+    {
+        if (g_opt.data == "random")
+            SF_CHECK(sf_fill_random_f64(d_in.get(), nelmt * nmTot, g_opt.seed, 0, nullptr));
+        else
+            SF_CHECK(sf_fill_sincos_f64(d_in.get(), nelmt, nmTot, nullptr));
+        SF_CHECK(sf_fill_basis_f64(d_basis0.get(), nm0, nq0, nullptr));
+        SF_CHECK(sf_fill_basis_f64(d_basis1.get(), nm1, nq1, nullptr));
+        SF_CHECK(sf_fill_basis_f64(d_basis2.get(), nm2, nq2, nullptr));
+    }
     HIP_CHECK(hipDeviceSynchronize());
 
     constexpr int NCOL        = 5;
@@ -61,20 +77,27 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     {
         times[v]   = std::numeric_limits<double>::max();
         results[v] = 0.0;
-        if (!g_opt.baselines && v != 3)
+        if ((!g_opt.baselines || kF32) && v != 3)
             continue;
         HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
         auto launch = [&]()
         {
-            if (variants[v] >= 0)
-                SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
-                                                     d_basis0.get(), d_basis1.get(), d_basis2.get(),
-                                                     d_in.get(), d_wsp.get(), d_out.get(), nullptr));
-#ifdef SF_WITH_ROCBLAS
+            if constexpr (kF32)
+                SF_CHECK(sf_bwdtrans_hex_f32(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(),
+                                             d_basis2.get(), d_in.get(), d_out.get(), nullptr));
             else
-                blas.hex(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(), d_basis2.get(),
-                         d_in.get(), d_wsp.get(), d_out.get());
+            {
+                if (variants[v] >= 0)
+                    SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
+                                                         d_basis0.get(), d_basis1.get(),
+                                                         d_basis2.get(), d_in.get(), d_wsp.get(),
+                                                         d_out.get(), nullptr));
+#ifdef SF_WITH_ROCBLAS
+                else
+                    blas.hex(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(), d_basis2.get(),
+                             d_in.get(), d_wsp.get(), d_out.get());
 #endif
+            }
         };
 #ifdef SF_WITH_ROCBLAS
         if (variants[v] < 0 && !blas.ok())
@@ -86,7 +109,10 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
         launch(); // first touch outside the timed loop
         HIP_CHECK(hipDeviceSynchronize());
         times[v] = time_min(launch, v >= 3 ? 1e30 : kSlowBudgetS);
-        SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
+        if constexpr (kF32)
+            SF_CHECK(sf_sumsq_f32(d_out.get(), nelmt * nqTot, &results[v], nullptr));
+        else
+            SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
     }
 
     // Display results (grammar of benchmark05.cc:1387-1420)
@@ -108,7 +134,7 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     std::cout << std::endl;
     std::cout << std::flush;
 
-    const double bytes = 8.0 * nelmt * (double)(nmTot + nqTot);
+    const double bytes = (double)sizeof(T) * nelmt * (double)(nmTot + nqTot);
     std::ostringstream r;
     r << std::setprecision(10) << "{\"nelmt\": " << nelmt << ", \"nq\": [" << nq0 << "," << nq1 << ","
       << nq2 << "], \"wave_gdof_s\": " << 1.0e-9 * nelmt * (double)nmTot / times[3]
@@ -141,14 +167,23 @@ int main(int argc, char **argv)
         std::cerr << "benchmark05: no HIP device visible; the kernels have no CPU fallback" << std::endl;
         return 4;
     }
+    const bool f32 = (g_opt.precision == "f32");
     if (g_opt.nelmt > 0)
-        run_test<double>((unsigned)g_opt.nelmt, nq0, nq1, nq2, threads, elblocks);
+    {
+        if (f32)
+            run_test<float>((unsigned)g_opt.nelmt, nq0, nq1, nq2, threads, elblocks);
+        else
+            run_test<double>((unsigned)g_opt.nelmt, nq0, nq1, nq2, threads, elblocks);
+    }
     else
         for (unsigned int size = 2 << 6; size < 2 << 20; size <<= 1)
         {
             if (g_opt.maxsize > 0 && size > g_opt.maxsize)
                 break;
-            run_test<double>(size, nq0, nq1, nq2, threads, elblocks);
+            if (f32)
+                run_test<float>(size, nq0, nq1, nq2, threads, elblocks);
+            else
+                run_test<double>(size, nq0, nq1, nq2, threads, elblocks);
         }
     g_json.write(g_opt.json, device_header() + ", \"benchmark\": \"benchmark05\"");
     (void)sf_shutdown();

@@ -116,6 +116,7 @@ struct Options
     bool baselines    = true;    // --no-baselines : only the flagship column is timed
     int variant       = SF_VARIANT_AUTO; // --variant auto|wave|mfma|... : kernel of the flagship column
     unsigned seed     = 0x5F3759DFu;
+    std::string precision = "f64"; // --precision f64|f32
 };
 
 inline Options parse(int argc, char **argv)
@@ -145,6 +146,8 @@ inline Options parse(int argc, char **argv)
             o.seed = (unsigned)std::strtoul(next("--seed").c_str(), nullptr, 0);
         else if (s == "--no-baselines")
             o.baselines = false;
+        else if (s == "--precision")
+            o.precision = next("--precision");
         else if (s == "--variant")
         {
             const std::string v = next("--variant");
