@@ -34,7 +34,7 @@ GOLDEN_NORM_1M = 17134.76235  # benchmark05/nq8x8x8.log:45 (nelmt 1 048 576, sin
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--elements-per-gpu", type=int, default=1 << 20,
                     help="weak scaling: elements owned by each rank (default 1 048 576)")
@@ -108,10 +108,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    # one process per GPU; SF_BENCH_BACKEND=gloo (rehearsal: several ranks may then share a GPU,
+    # the scalar reductions go through CPU tensors) -- default nccl = RCCL over xGMI
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rdev = dev if backend == "nccl" else torch.device("cpu")   # where the reduced scalars live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     sf = ge.load_package()
     from gpu_benchmarking_amd import shard
@@ -135,8 +143,8 @@ def main():
         sf.bwdtrans_hex((nq,) * 3, b, b, b, x, out=out)
 
     wall, evs = time_steps(step, args.steps, args.warmup, torch, dist, world)
-    tmax = torch.tensor([wall, evs], dtype=torch.float64, device=dev)
-    checksum = torch.tensor([sf.sumsq(out)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall, evs], dtype=torch.float64, device=rdev)
+    checksum = torch.tensor([sf.sumsq(out)], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(checksum, op=dist.ReduceOp.SUM)

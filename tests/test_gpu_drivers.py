@@ -91,6 +91,31 @@ def test_benchmark02_and_03_device_columns(pkg, golden):
             assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
 
 
+def test_bench_two_ranks_rehearsal(pkg, tmp_path):
+    """bench.py's N>1 path on real hardware: 2 ranks share the one GPU of this box, scalar reductions
+    over gloo (SF_BENCH_BACKEND); checks the contract keys and that the shards add up."""
+    import sys
+    env = dict(os.environ, SF_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "1", "--total-elements", "200001"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["dtype"] == "f64"
+    assert rec["config"]["total_elements"] == 200001 and rec["value"] > 1.0
+    # the two shards together are the single-rank batch: same checksum as one rank over all elements
+    x = pkg.fill_random(200001 * 343, 0x5F3759DF, 0)
+    b = pkg.fill_basis(7, 8)
+    import math
+    full = math.sqrt(pkg.sumsq(pkg.bwdtrans_hex((8, 8, 8), b, b, b, x)))
+    assert abs(rec["checksum_norm"] - full) <= 1e-12 * full
+
+
 def test_anisotropic_cli(pkg, oracle):
     """nq0 != nq1 != nq2 takes the generic path; norm checked against the oracle."""
     import math
