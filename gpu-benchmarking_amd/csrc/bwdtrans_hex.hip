@@ -56,7 +56,9 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
 template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)
 {
     using C = HexCfg<NQ>;
-    return launch_hex_wave<NQ, 2 * C::EC, C::WPB, C::BM, C::MW, C::KM, OUT_LDS, 0, float>(a, s);
+    // half the register footprint of fp64 -> twice the waves per SIMD (capped at 4), one chunk per wave
+    constexpr int MW = C::MW >= 2 ? 4 : 2;
+    return launch_hex_wave<NQ, 2 * C::EC, C::WPB, C::BM, MW, 1, OUT_LDS, 0, float>(a, s);
 }
 
 int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s)

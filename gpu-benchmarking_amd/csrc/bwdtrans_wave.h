@@ -60,6 +60,16 @@ template <typename T> struct VecOf
     typedef T type __attribute__((ext_vector_type(W)));
 };
 
+// fused multiply-add in the scalar type (calling the double builtin on floats converts both ways)
+__device__ __forceinline__ double fma_t(double a, double b, double c)
+{
+    return __builtin_fma(a, b, c);
+}
+__device__ __forceinline__ float fma_t(float a, float b, float c)
+{
+    return __builtin_fmaf(a, b, c);
+}
+
 // exchange a double with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ double swap_adjacent(double v)
 {
@@ -257,22 +267,32 @@ __device__ __forceinline__ void contract(const T (&u)[NPASS][NIN], T (&acc)[NPAS
     // kernel argument to get s_load) so the loads also stay inside the chunk loop.
     int zero = 0;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    // ring of operand rows: scalar loads come from the K-cache / L2 (longer latency) -> 2 rows ahead
-    constexpr int PFD = (BMODE == BASIS_SMEM) ? 2 : 1, RING = PFD + 1;
+    // Ring of operand rows, one row ahead.  Scalar loads return OUT OF ORDER, so the wait for row m is
+    // always lgkmcnt(0): it would also wait for a row requested just before it.  Hence the order per
+    // row: (1) touch row m (the wait lands here, covering only loads issued a whole row of FMAs ago),
+    // (2) request row m+1, (3) the FMAs of row m (the new request is in flight underneath them).
+    constexpr int RING = 2;
     T b[RING][NOUT];
 #pragma unroll
-    for (int r = 0; r < PFD && r < NIN; ++r)
-#pragma unroll
-        for (int n = 0; n < NOUT; ++n)
-            b[r][n] = bas[zero + r * NOUT + n];
+    for (int n = 0; n < NOUT; ++n)
+        b[0][n] = bas[zero + n];
 #pragma unroll
     for (int m = 0; m < NIN; ++m)
     {
-        if (m + PFD < NIN)
+        if constexpr (BMODE == BASIS_SMEM)
         {
 #pragma unroll
             for (int n = 0; n < NOUT; ++n)
-                b[(m + PFD) % RING][n] = bas[zero + (m + PFD) * NOUT + n];
+                asm volatile("" : "+s"(zero) : "s"(b[m % RING][n]));
+        }
+        if (m + 1 < NIN)
+        {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n)
+                b[(m + 1) % RING][n] = bas[zero + (m + 1) * NOUT + n];
+            // keep the request ABOVE this row's FMAs (the machine scheduler otherwise sinks it to just
+            // before the next wait and the latency is exposed again)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int n = 0; n < NOUT; ++n)
@@ -280,7 +300,7 @@ __device__ __forceinline__ void contract(const T (&u)[NPASS][NIN], T (&acc)[NPAS
 #pragma unroll
             for (int s = 0; s < NPASS; ++s)
                 acc[s][n] = (m == 0) ? u[s][0] * b[0][n]
-                                     : __builtin_fma(u[s][m], b[m % RING][n], acc[s][n]);
+                                     : fma_t(u[s][m], b[m % RING][n], acc[s][n]);
         }
         // order fence: the next row's operand loads (addressed through `zero`) may not be issued
         // before this row's FMAs, and this row's FMAs may not sink below them

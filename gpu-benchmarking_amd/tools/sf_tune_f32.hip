@@ -1,0 +1,125 @@
+// sf_tune_f32.hip -- configuration sweep of the T = float instantiations (development tool).
+#include "../csrc/wave_launch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+namespace sf
+{
+int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s);
+int fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
+int fill_basis_f32(float *b, size_t nm, size_t nq, hipStream_t s);
+} // namespace sf
+using namespace sf;
+
+#define CK(x)                                                                                      \
+    do                                                                                             \
+    {                                                                                              \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+        {                                                                                          \
+            std::fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__);    \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+
+static int g_reps = 15;
+static hipEvent_t g_e0, g_e1;
+
+static void run(const char *label, double dof, double bytes, float *out, size_t nout,
+                const std::function<int()> &launch)
+{
+    int rc = launch();
+    CK(hipDeviceSynchronize());
+    if (rc != 0)
+    {
+        std::printf("%-40s rc=%d\n", label, rc);
+        return;
+    }
+    std::vector<double> t;
+    for (int r = 0; r < g_reps; ++r)
+    {
+        CK(hipEventRecord(g_e0, 0));
+        launch();
+        CK(hipEventRecord(g_e1, 0));
+        CK(hipEventSynchronize(g_e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+        t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    double sum = 0;
+    for (double v : t)
+        sum += v;
+    double ss = 0;
+    sumsq_f32_blocking(out, nout, &ss, 0);
+    std::printf("%-40s min %8.4f mean %8.4f ms | %7.2f / %7.2f GDOF/s | %7.1f GB/s | norm %.8g\n", label,
+                t[0], sum / t.size(), dof / (t[0] * 1e-3) * 1e-9, dof / (sum / t.size() * 1e-3) * 1e-9,
+                bytes / (t[0] * 1e-3) * 1e-9, std::sqrt(ss));
+    std::fflush(stdout);
+}
+
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS>
+void hex_case(const HexArgsT<float> &a)
+{
+    char label[96];
+    std::snprintf(label, sizeof label, "hex f32 nq%d EC%d WPB%d %s MW%d K%d o%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT);
+    const double nm = NQ - 1;
+    run(label, a.nelmt * nm * nm * nm, a.nelmt * 4.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
+        a.nelmt * (size_t)NQ * NQ * NQ,
+        [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, 0, float>(a, 0); });
+}
+
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS>
+void quad_case(const QuadArgsT<float> &a)
+{
+    char label[96];
+    std::snprintf(label, sizeof label, "quad f32 nq%d EC%d WPB%d %s MW%d K%d o%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT);
+    const double nm = NQ - 1;
+    run(label, a.nelmt * nm * nm, a.nelmt * 4.0 * (nm * nm + (double)NQ * NQ), a.out,
+        a.nelmt * (size_t)NQ * NQ,
+        [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, 0, float>(a, 0); });
+}
+
+int main(int argc, char **argv)
+{
+    const size_t nelmt = argc > 1 ? (size_t)std::atoll(argv[1]) : (size_t)1 << 20;
+    g_reps             = argc > 2 ? std::atoi(argv[2]) : 15;
+    CK(hipEventCreate(&g_e0));
+    CK(hipEventCreate(&g_e1));
+    constexpr int NQ = 8, NM = 7;
+    float *b, *in, *out;
+    CK(hipMalloc((void **)&b, sizeof(float) * NM * NQ));
+    CK(hipMalloc((void **)&in, sizeof(float) * nelmt * NM * NM * NM));
+    CK(hipMalloc((void **)&out, sizeof(float) * nelmt * NQ * NQ * NQ));
+    fill_basis_f32(b, NM, NQ, 0);
+    fill_random_f32(in, nelmt * NM * NM * NM, 0x5F3759DF, 0, 0);
+    CK(hipDeviceSynchronize());
+    HexArgsT<float> h{b, b, b, in, nullptr, out, nelmt};
+    hex_case<8, 8, 4, BASIS_SMEM, 2, 2>(h);
+    hex_case<8, 4, 4, BASIS_SMEM, 2, 2>(h);
+    hex_case<8, 4, 4, BASIS_SMEM, 4, 2>(h);
+    hex_case<8, 4, 4, BASIS_SMEM, 4, 1>(h);
+    hex_case<8, 4, 4, BASIS_SMEM, 4, 4>(h);
+    hex_case<8, 8, 4, BASIS_SMEM, 4, 1>(h);
+    hex_case<8, 8, 4, BASIS_SMEM, 4, 2>(h);
+    hex_case<8, 8, 4, BASIS_LDS, 4, 2>(h);
+    hex_case<8, 16, 4, BASIS_SMEM, 2, 1>(h);
+    hex_case<8, 8, 8, BASIS_SMEM, 4, 2>(h);
+    hex_case<8, 4, 8, BASIS_SMEM, 4, 2>(h);
+    hex_case<8, 8, 4, BASIS_SMEM, 4, 2, OUT_ST8>(h);
+    QuadArgsT<float> q{b, b, in, nullptr, out, nelmt};
+    quad_case<8, 16, 4, BASIS_SMEM, 2, 1>(q);
+    quad_case<8, 16, 4, BASIS_SMEM, 4, 1>(q);
+    quad_case<8, 32, 4, BASIS_SMEM, 2, 1>(q);
+    quad_case<8, 32, 4, BASIS_SMEM, 4, 1>(q);
+    quad_case<8, 32, 4, BASIS_SMEM, 4, 2>(q);
+    quad_case<8, 64, 4, BASIS_SMEM, 2, 1>(q);
+    return 0;
+}
