@@ -15,5 +15,5 @@ it is missing.
 from . import capi, logfmt, shard  # noqa: F401
 from .bwdtrans import (  # noqa: F401
     bwdtrans_hex, bwdtrans_quad, sumsq, fill_sincos, fill_basis, fill_random, fill_l2norm,
-    stream_copy, device_info, fill_vecadd, vector_add, fill_matvec, matvec, hex_wsp_doubles, quad_wsp_doubles, VARIANTS,
+    stream_copy, device_info, interleave64, bwdtrans_hex_interleaved, fill_vecadd, vector_add, fill_matvec, matvec, hex_wsp_doubles, quad_wsp_doubles, VARIANTS,
 )

@@ -115,6 +115,34 @@ def bwdtrans_quad(nq, basis0, basis1, inp, out=None, variant="auto", wsp=None, s
     return out
 
 
+def interleave64(src, nelmt, n, inverse=False, stream=None):
+    """[e][n] -> [(e/64)][n][e%64] (padded to whole groups of 64 elements), or back."""
+    padded = (nelmt + 63) // 64 * 64
+    dst = torch.zeros((nelmt if inverse else padded) * n, dtype=torch.float64, device=src.device)
+    with torch.cuda.device(src.device):
+        capi.check(capi.lib().sf_interleave64_f64(_dev_f64(src, "src"), _dev_f64(dst, "dst"), nelmt,
+                                                  n, 1 if inverse else 0, _stream(stream)),
+                   "sf_interleave64_f64")
+    return dst
+
+
+def bwdtrans_hex_interleaved(nq, basis0, basis1, basis2, in_il, nelmt, stream=None):
+    """Thread-per-element kernel on the wave-64 interleaved layout (the corrected `_Coa`,
+    benchmark05/benchmark05.cc:104-201).  Returns out_il (interleaved)."""
+    nq0, nq1, nq2 = (int(x) for x in nq)
+    padded = (nelmt + 63) // 64 * 64
+    out = torch.empty(padded * nq0 * nq1 * nq2, dtype=torch.float64, device=in_il.device)
+    wsp = torch.empty(padded * ((nq1 - 1) * (nq2 - 1) + (nq2 - 1)), dtype=torch.float64,
+                      device=in_il.device)
+    with torch.cuda.device(in_il.device):
+        rc = capi.lib().sf_bwdtrans_hex_f64_interleaved(
+            nq0, nq1, nq2, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
+            _dev_f64(basis2, "basis2"), _dev_f64(in_il, "in_il"), _dev_f64(wsp, "wsp"),
+            _dev_f64(out, "out_il"), _stream(stream))
+    capi.check(rc, "sf_bwdtrans_hex_f64_interleaved")
+    return out
+
+
 def sumsq(x, stream=None):
     """sum x^2 (blocking; deterministic) -- the reference's thrust::transform_reduce."""
     res = ctypes.c_double(0.0)

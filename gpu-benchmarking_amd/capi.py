@@ -30,6 +30,8 @@ SYMBOLS = {
     "sf_fill_random_f64": (_i, [_vp, _sz, _u64, _u64, _vp]),
     "sf_fill_l2norm_f64": (_i, [_vp, _sz, _vp]),
     "sf_stream_copy_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "sf_bwdtrans_hex_f64_interleaved": (_i, [_u, _u, _u, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sf_interleave64_f64": (_i, [_vp, _vp, _sz, _sz, _i, _vp]),
     "sf_bwdtrans_hex_f32": (_i, [_u, _u, _u, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sf_bwdtrans_quad_f32": (_i, [_u, _u, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sf_sumsq_f32": (_i, [_vp, _sz, ctypes.POINTER(ctypes.c_double), _vp]),

@@ -230,6 +230,89 @@ __global__ __launch_bounds__(128) void quad_thread_kernel(unsigned nq0, unsigned
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-64 interleaved element layout: data[(e/64)][f][e%64].  One thread per element,
+// fused nest, every global access of a wavefront is 64 consecutive doubles.  This is the decomposition of
+// the reference's BwdTransHexKernel_Coa (benchmark05/benchmark05.cc:104-201) with the wavefront width of
+// CDNA (64, the reference hard-codes 32) and WITHOUT its output-index bug (its output base omits the
+// factor nq2, :193-194, so blocks overlap and the published column-7 norm is wrong).
+__global__ __launch_bounds__(256) void hex_interleaved_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
+                                                              HexArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *lds = reinterpret_cast<double *>(lds_raw);
+    const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
+    const uint64_t nmt = (uint64_t)nm0 * nm1 * nm2, nqt = (uint64_t)nq0 * nq1 * nq2;
+    const unsigned nrq = nm1 * nm2;
+    double *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
+    for (unsigned x = threadIdx.x; x < nm0 * nq0; x += blockDim.x)
+        sb0[x] = a.b0[x];
+    for (unsigned x = threadIdx.x; x < nm1 * nq1; x += blockDim.x)
+        sb1[x] = a.b1[x];
+    for (unsigned x = threadIdx.x; x < nm2 * nq2; x += blockDim.x)
+        sb2[x] = a.b2[x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nelmt; e += stride)
+    {
+        const uint64_t grp = e / kWave, lane = e % kWave;
+        const double *ine = a.in + grp * kWave * nmt + lane;          // + 64*f
+        double *oute      = a.out + grp * kWave * nqt + lane;         // + 64*g
+        double *s0        = a.wsp + grp * kWave * (nrq + nm2) + lane; // + 64*x
+        double *s1        = s0 + (uint64_t)kWave * nrq;
+        for (unsigned i = 0; i < nq0; ++i)
+        {
+            for (unsigned rq = 0; rq < nrq; ++rq)
+            {
+                double t = 0.0;
+                for (unsigned p = 0; p < nm0; ++p)
+                    t += ine[(uint64_t)kWave * (rq * nm0 + p)] * sb0[p * nq0 + i];
+                s0[(uint64_t)kWave * rq] = t;
+            }
+            for (unsigned j = 0; j < nq1; ++j)
+            {
+                for (unsigned r = 0; r < nm2; ++r)
+                {
+                    double t = 0.0;
+                    for (unsigned q = 0; q < nm1; ++q)
+                        t += s0[(uint64_t)kWave * (r * nm1 + q)] * sb1[q * nq1 + j];
+                    s1[(uint64_t)kWave * r] = t;
+                }
+                for (unsigned k = 0; k < nq2; ++k)
+                {
+                    double t = 0.0;
+                    for (unsigned r = 0; r < nm2; ++r)
+                        t += s1[(uint64_t)kWave * r] * sb2[r * nq2 + k];
+                    oute[(uint64_t)kWave * ((k * nq1 + j) * nq0 + i)] = t;
+                }
+            }
+        }
+    }
+}
+
+// element-major [e][n] <-> wave-64 interleaved [(e/64)][n][e%64]
+__global__ __launch_bounds__(256) void interleave64_kernel(const double *__restrict__ src,
+                                                           double *__restrict__ dst, uint64_t nelmt,
+                                                           uint64_t n, int inverse)
+{
+    const uint64_t total  = (nelmt + kWave - 1) / kWave * kWave * n; // padded to whole groups
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride)
+    {
+        // x enumerates the interleaved side contiguously inside full groups: (grp, f, lane)
+        const uint64_t grp = x / (kWave * n), rem = x - grp * kWave * n;
+        const uint64_t f = rem / kWave, lane = rem - f * kWave;
+        const uint64_t e = grp * kWave + lane;
+        if (e >= nelmt)
+            continue;
+        const uint64_t il = grp * kWave * n + f * kWave + lane, em = e * n + f;
+        if (inverse)
+            dst[em] = src[il];
+        else
+            dst[il] = src[em];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline int launch_rc()
 {
     hipError_t e = hipGetLastError();
@@ -333,6 +416,35 @@ int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, co
                        hipStream_t s)
 {
     return launch_hex_generic_t<double>(variant, nq0, nq1, nq2, a, s);
+}
+
+int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s)
+{
+    const size_t nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
+    const size_t lds = sizeof(double) * (nm0 * nq0 + nm1 * nq1 + nm2 * nq2);
+    if (lds > kMaxDynLds)
+        return SF_ENOTBUILT;
+    if (!a.wsp)
+        return SF_EINVAL;
+    const unsigned cu     = (unsigned)device_info().num_cu;
+    const uint64_t blocks = (a.nelmt + 255) / 256;
+    hex_interleaved_kernel<<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 256, lds, s>>>(nq0, nq1,
+                                                                                            nq2, a);
+    return launch_rc();
+}
+
+int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
+                        hipStream_t s)
+{
+    // the interleaved side is padded to whole groups of 64 elements
+    const uint64_t padded = (nelmt + kWave - 1) / kWave * kWave;
+    const uint64_t total  = padded * n;
+    if (total == 0)
+        return SF_OK;
+    const uint64_t want = (total + 255) / 256, cap = (uint64_t)device_info().num_cu * 32;
+    interleave64_kernel<<<(unsigned)(want > cap ? cap : want), 256, 0, s>>>(src, dst, nelmt, n,
+                                                                            inverse);
+    return launch_rc();
 }
 int launch_hex_generic_f32(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
                            const HexArgsT<float> &a, hipStream_t s)

@@ -27,6 +27,9 @@ int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
 int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
 int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
 int release_workspaces();
+int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
+int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
+                        hipStream_t s);
 int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s);
 int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s);
 int launch_hex_generic_f32(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
@@ -190,6 +193,30 @@ int sf_bwdtrans_quad_f64(unsigned nq0, unsigned nq1, size_t nelmt, const double 
 {
     return sf_bwdtrans_quad_f64_variant(SF_VARIANT_AUTO, nq0, nq1, nelmt, basis0, basis1, in,
                                         nullptr, out, stream);
+}
+
+int sf_bwdtrans_hex_f64_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                                    const double *basis0, const double *basis1, const double *basis2,
+                                    const double *in_il, double *wsp_il, double *out_il, void *stream)
+{
+    if (nq0 < 2 || nq1 < 2 || nq2 < 2)
+        return SF_EINVAL;
+    if (nelmt == 0)
+        return SF_OK;
+    if (!basis0 || !basis1 || !basis2 || !in_il || !wsp_il || !out_il)
+        return SF_EINVAL;
+    if (!aligned(in_il, 8) || !aligned(out_il, 8) || !aligned(wsp_il, 8))
+        return SF_EALIGN;
+    HexArgs a{basis0, basis1, basis2, in_il, wsp_il, out_il, (uint64_t)nelmt};
+    return launch_hex_interleaved(nq0, nq1, nq2, a, (hipStream_t)stream);
+}
+
+int sf_interleave64_f64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
+                        void *stream)
+{
+    if ((!src || !dst) && nelmt * n)
+        return SF_EINVAL;
+    return launch_interleave64(src, dst, nelmt, n, inverse, (hipStream_t)stream);
 }
 
 // ---- fp32 (T = float) ------------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 //   3 HIP (block/elmt LDS)  one workgroup per element, all in LDS     (:510-617)
 //   4 HIP (wave/chunk)      flagship: one wavefront streams chunks    (sf_bwdtrans_hex_f64)
 //   5 rocBLAS               1 DGEMM + 2 strided-batched DGEMMs, global wsp (cuBLAS column :1062-1171)
+//   6 HIP (thread/elmt il64) one thread per element on the wave-64 interleaved layout: the `_Coa`
+//                           decomposition (:104-201) without its output-index bug (:193-194)
 // `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4), --precision f64|f32
@@ -64,11 +66,25 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
     }
     HIP_CHECK(hipDeviceSynchronize());
 
-    constexpr int NCOL        = 5;
+    constexpr int NCOL        = 6;
     const int variants[NCOL]  = {SF_VARIANT_THREAD, SF_VARIANT_BLOCK_GLB, SF_VARIANT_BLOCK_LDS,
-                                 g_opt.variant, -1 /* rocBLAS */};
+                                 g_opt.variant, -1 /* rocBLAS */, -2 /* interleaved layout */};
     const char *names[NCOL]   = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
-                                 "HIP (wave/chunk)", "rocBLAS"};
+                                 "HIP (wave/chunk)", "rocBLAS", "HIP (thread/elmt il64)"};
+    // column 6 works on its own copies of in/out in the interleaved layout (as the reference keeps
+    // d_in_coa next to d_in, benchmark05.cc:1240); padded to whole groups of 64 elements
+    const size_t padded = (nelmt + 63) / 64 * 64;
+    const bool il_on    = g_opt.baselines && !kF32;
+    DeviceBuffer<double> d_in_il(il_on ? padded * nmTot : 0), d_out_il(il_on ? padded * nqTot : 0);
+    DeviceBuffer<double> d_wsp_il(il_on ? padded * ((size_t)nm1 * nm2 + nm2) : 0);
+    if constexpr (!kF32)
+    {
+        if (il_on)
+        {
+            SF_CHECK(sf_interleave64_f64(d_in.get(), d_in_il.get(), nelmt, nmTot, 0, nullptr));
+            HIP_CHECK(hipMemsetAsync(d_out_il.get(), 0, padded * nqTot * sizeof(double), nullptr));
+        }
+    }
     double times[NCOL], results[NCOL];
 #ifdef SF_WITH_ROCBLAS
     static RocblasColumn blas;
@@ -87,30 +103,37 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
                                              d_basis2.get(), d_in.get(), d_out.get(), nullptr));
             else
             {
-                if (variants[v] >= 0)
+                if (variants[v] == -2)
+                    SF_CHECK(sf_bwdtrans_hex_f64_interleaved(nq0, nq1, nq2, nelmt, d_basis0.get(),
+                                                             d_basis1.get(), d_basis2.get(),
+                                                             d_in_il.get(), d_wsp_il.get(),
+                                                             d_out_il.get(), nullptr));
+                else if (variants[v] >= 0)
                     SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
                                                          d_basis0.get(), d_basis1.get(),
                                                          d_basis2.get(), d_in.get(), d_wsp.get(),
                                                          d_out.get(), nullptr));
 #ifdef SF_WITH_ROCBLAS
-                else
+                else if (variants[v] == -1)
                     blas.hex(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(), d_basis2.get(),
                              d_in.get(), d_wsp.get(), d_out.get());
 #endif
             }
         };
 #ifdef SF_WITH_ROCBLAS
-        if (variants[v] < 0 && !blas.ok())
+        if (variants[v] == -1 && !blas.ok())
             continue;
 #else
-        if (variants[v] < 0)
+        if (variants[v] == -1)
             continue;
 #endif
         launch(); // first touch outside the timed loop
         HIP_CHECK(hipDeviceSynchronize());
-        times[v] = time_min(launch, v >= 3 ? 1e30 : kSlowBudgetS);
+        times[v] = time_min(launch, (v == 3 || v == 4) ? 1e30 : kSlowBudgetS);
         if constexpr (kF32)
             SF_CHECK(sf_sumsq_f32(d_out.get(), nelmt * nqTot, &results[v], nullptr));
+        else if (variants[v] == -2) // padded lanes were zeroed and are never written
+            SF_CHECK(sf_sumsq_f64(d_out_il.get(), padded * nqTot, &results[v], nullptr));
         else
             SF_CHECK(sf_sumsq_f64(d_out.get(), nelmt * nqTot, &results[v], nullptr));
     }

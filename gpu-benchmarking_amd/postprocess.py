@@ -25,6 +25,8 @@ except ImportError:  # run as a script
 OUR_LABELS = {
     ("DOF/s", 5): ["HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
                    "HIP (wave/chunk)", "rocBLAS"],
+    ("DOF/s", 6): ["HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                   "HIP (wave/chunk)", "rocBLAS", "HIP (thread/elmt il64)"],
     ("GB/s", 2): ["Host (OpenMP)", "HIP (vl)"],
 }
 REFERENCE_LABELS = {

@@ -122,6 +122,20 @@ int sf_fill_l2norm_f64(double *x, size_t n, void *stream);
 int sf_stream_copy_f64(const double *src, double *dst, size_t n, void *stream);
 
 /*
+ * Wave-64 interleaved element layout: data[(e/64)][f][e%64], padded to whole groups of
+ * 64 elements.  One thread per element with fully coalesced accesses: the decomposition of the
+ * reference's BwdTransHexKernel_Coa (benchmark05/benchmark05.cc:104-201, launch :1283-1286) for a
+ * 64-wide wavefront and without its output-index bug (:193-194).  Sizes in doubles, G = ceil(nelmt/64)*64:
+ *   in_il G*nm0*nm1*nm2, out_il G*nq0*nq1*nq2, wsp_il G*(nm1*nm2 + nm2).
+ * sf_interleave64_f64 converts element-major [e][n] -> interleaved (inverse = 0) or back (inverse = 1).
+ */
+int sf_bwdtrans_hex_f64_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                                    const double *basis0, const double *basis1, const double *basis2,
+                                    const double *in_il, double *wsp_il, double *out_il, void *stream);
+int sf_interleave64_f64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
+                        void *stream);
+
+/*
  * fp32: the reference's kernels are templates on T but only T = double is ever
  * instantiated (benchmark05/benchmark05.cc:15, 1439); these are the T = float instantiations of the
  * same kernels (float4 lanes).  sumsq accumulates in double.  Same layouts and error codes.

@@ -35,7 +35,7 @@ def test_benchmark05_default_cli_sweep(pkg, golden, tmp_path):
     assert lines[:4] == ["-" * 32, "Benchmark05 : BwdTrans (3D)     ", "-" * 32,
                          "BwdTrans (NQ = 8, 8, 8)"]
     log = pkg.logfmt.parse_log(out)
-    assert log.kind == "DOF/s" and log.ncols == 5 and log.title == "BwdTrans (NQ = 8, 8, 8)"
+    assert log.kind == "DOF/s" and log.ncols == 6 and log.title == "BwdTrans (NQ = 8, 8, 8)"
     assert log.sizes == [float(128 << k) for k in range(8)]
     want = {r["n"]: float(r["norm"]) for r in golden["hex"]["8"]["rows"]}
     for size, norms in zip(log.sizes, log.norms):
@@ -125,4 +125,4 @@ def test_anisotropic_cli(pkg, oracle):
     ref = oracle.bwdtrans_hex((3, 5, 4), 1000, *b, oracle.fill_sincos(1000, 2 * 4 * 3))
     norm = math.sqrt(oracle.sumsq(ref))
     for v in log.norms[0]:
-        assert abs(v - norm) <= 1e-9 * norm           # all five columns incl. rocBLAS
+        assert abs(v - norm) <= 1e-9 * norm           # all six columns incl. rocBLAS, interleaved

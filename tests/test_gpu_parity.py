@@ -212,6 +212,25 @@ def test_vecadd_and_matvec(sf, oracle, golden, torch_mod):
     assert oracle.rel_err(_np(sf.matvec(37, 101, a, x)), yo) <= TOL
 
 
+def test_interleaved_layout_variant(sf, oracle):
+    """Wave-64 interleaved layout (corrected `_Coa`): layout round trip is exact, results match the
+    oracle, including a ragged last group and anisotropic extents."""
+    for nq, nelmt in (((8, 8, 8), 200), ((4, 4, 4), 64), ((3, 5, 4), 131), ((2, 2, 2), 1)):
+        nm = [q - 1 for q in nq]
+        nmt, nqt = nm[0] * nm[1] * nm[2], nq[0] * nq[1] * nq[2]
+        bs = [sf.fill_random(nm[d] * nq[d], 70 + d) for d in range(3)]
+        x = sf.fill_random(nelmt * nmt, nelmt)
+        x_il = sf.interleave64(x, nelmt, nmt)
+        assert np.array_equal(_np(sf.interleave64(x_il, nelmt, nmt, inverse=True)), _np(x))
+        # spot-check the layout definition: element e, mode f sits at (e//64)*64*nmt + f*64 + e%64
+        e, f = nelmt - 1, nmt - 1
+        assert _np(x_il)[(e // 64) * 64 * nmt + f * 64 + e % 64] == _np(x)[e * nmt + f]
+        out_il = sf.bwdtrans_hex_interleaved(nq, *bs, x_il, nelmt)
+        out = sf.interleave64(out_il, nelmt, nqt, inverse=True)
+        ref = oracle.bwdtrans_hex(nq, nelmt, *[_np(b) for b in bs], _np(x))
+        assert oracle.rel_err(_np(out), ref) <= TOL, (nq, nelmt)
+
+
 TOL32 = 2e-5   # fp32: eps = 6e-8, sums of up to 3*31 products with cancellation
 
 
