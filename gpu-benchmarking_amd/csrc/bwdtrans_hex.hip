@@ -27,9 +27,21 @@ SF_HEX_CFG(9,  2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 277 / 274
 SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 310 / 306
 #undef SF_HEX_CFG
 
+// Small batches: with the tuned (fat) chunks a batch of a few thousand elements occupies only a fraction
+// of the 256 CUs, so below ~2 workgroups per CU a fine-grained instantiation is launched instead:
+// quarter-size chunks (kept even: 16-byte alignment of the chunk), one wave per workgroup, one chunk per wave.
+template <int NQ> struct HexSmall
+{
+    static constexpr int EC  = (HexCfg<NQ>::EC / 4 + 1) / 2 * 2 < 2 ? 2 : (HexCfg<NQ>::EC / 4 + 1) / 2 * 2;
+    static constexpr int OUT = HexCfg<NQ>::OUT;
+};
+
 template <int NQ> static int go(const HexArgs &a, hipStream_t s)
 {
     using C = HexCfg<NQ>;
+    constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
+    if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
+        return launch_hex_wave<NQ, HexSmall<NQ>::EC, 1, C::BM, C::MW, 1, HexSmall<NQ>::OUT>(a, s);
     return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 

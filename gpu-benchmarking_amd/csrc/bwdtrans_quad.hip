@@ -31,9 +31,18 @@ SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16); // 325 / 302
 SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16); // 118 / 117: VALU-issue-bound (MFMA path: next)
 #undef SF_QUAD_CFG
 
+// small batches: see bwdtrans_hex.hip (HexSmall)
+template <int NQ> struct QuadSmall
+{
+    static constexpr int EC = (QuadCfg<NQ>::EC / 4 + 1) / 2 * 2 < 2 ? 2 : (QuadCfg<NQ>::EC / 4 + 1) / 2 * 2;
+};
+
 template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
 {
     using C = QuadCfg<NQ>;
+    constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
+    if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
+        return launch_quad_wave<NQ, QuadSmall<NQ>::EC, 1, C::BM, C::MW, 1, C::OUT>(a, s);
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
 }
 
