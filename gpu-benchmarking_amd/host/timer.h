@@ -1,39 +1,46 @@
-// timer.h -- host wall-clock stopwatch with the interface the reference harness uses
-// (utils/timer.h:3-45: start() / stop() / elapsedNanoseconds() / elapsedSeconds()).
-// Written for this project: a monotonic clock (the reference mixes system_clock and
-// high_resolution_clock, which only compiles where they alias) and <chrono> included here.
+// timer.h -- host wall-clock stopwatch for the benchmark drivers.
+//
+// Interface contract (what the reference harness calls on its Timer, utils/timer.h:3-45):
+//     Timer t;  t.start();  <launch + sync>;  t.stop();  double s = t.elapsedSeconds();
+// Own implementation: monotonic steady_clock (the reference mixes system_clock members with
+// high_resolution_clock values and only compiles where the two alias), <chrono> included here, reading
+// a running watch is allowed, plus min-tracking helpers used by the min-of-40 protocol.
 #pragma once
 
 #include <chrono>
+#include <limits>
 
 class Timer
 {
+    using clock = std::chrono::steady_clock;
+    using ns    = std::chrono::nanoseconds;
+
 public:
-    void start()
-    {
-        m_begin   = clock::now();
-        m_running = true;
-    }
+    void start() { m_t0 = clock::now(); m_live = true; }
+    void stop() { m_t1 = clock::now(); m_live = false; }
 
-    void stop()
-    {
-        m_end     = clock::now();
-        m_running = false;
-    }
-
+    // nanoseconds between start() and stop() (or now, while running)
     double elapsedNanoseconds() const
     {
-        const clock::time_point end = m_running ? clock::now() : m_end;
-        return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(end - m_begin).count();
+        return (double)std::chrono::duration_cast<ns>((m_live ? clock::now() : m_t1) - m_t0).count();
     }
+    double elapsedMilliseconds() const { return 1.0e-6 * elapsedNanoseconds(); }
+    double elapsedSeconds() const { return 1.0e-9 * elapsedNanoseconds(); }
 
-    double elapsedSeconds() const
+    // stop, fold the lap into the running minimum, return the lap in seconds
+    double lapMin()
     {
-        return elapsedNanoseconds() * 1.0e-9;
+        stop();
+        const double s = elapsedSeconds();
+        if (s < m_best)
+            m_best = s;
+        return s;
     }
+    double best() const { return m_best; }
+    void resetBest() { m_best = std::numeric_limits<double>::max(); }
 
 private:
-    using clock = std::chrono::steady_clock;
-    clock::time_point m_begin{}, m_end{};
-    bool m_running = false;
+    clock::time_point m_t0{}, m_t1{};
+    double m_best = std::numeric_limits<double>::max();
+    bool m_live   = false;
 };
