@@ -158,14 +158,6 @@ __global__ __launch_bounds__(kRedThreads) void sumsq_partial_scalar_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_copy_kernel(const double2_t *__restrict__ src,
-                                                          double2_t *__restrict__ dst, uint64_t nv)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
-}
-
 // One 16-byte lane per thread and a grid that covers the whole array (no grid-stride loop): on this
 // part a dispatcher-ordered huge grid streams ~6.6 TB/s where a persistent grid-stride copy tops out
 // at ~5.7 TB/s (profiles/r01/membench1.log).

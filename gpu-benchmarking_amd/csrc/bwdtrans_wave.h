@@ -8,29 +8,33 @@
 //  * Work unit = a CHUNK of EC consecutive elements owned by ONE 64-lane wavefront.  No workgroup
 //    barrier in the element loop (the reference pays 4 __syncthreads per element); lanes of the wave
 //    hand data to each other through a private LDS slab, ordered by wave_lds_fence().
-//  * Persistent grid: wave w handles chunks w, w+W, w+2W ...; the bases are staged in LDS once per
-//    workgroup (the reference reloads them per block = per element).
-//  * HBM -> registers with flat, coalesced 16-B-per-lane loads of the whole chunk (EC*nm^d doubles
-//    are contiguous), issued one chunk AHEAD and parked in VGPRs while the current chunk is computed
-//    (software pipelining without LDS double buffers) -> LDS slab.
+//  * Chunk -> wave mapping (template KMAP): K > 0 (shipped) = short-lived waves, wave w takes the K
+//    consecutive chunks [wK, wK+K) and the grid covers the batch -- the hardware dispatcher keeps the DRAM
+//    access front tight, 10-15 % faster on this read/write mix than KMAP = 0, a persistent grid where wave
+//    w takes chunks w, w+W, w+2W ... (profiles/r01/tune_nq8_b_kmap_st16.log).
+//  * HBM -> registers with flat, coalesced 16-B-per-lane non-temporal loads of the whole chunk (EC*nm^d
+//    scalars are contiguous), issued one chunk AHEAD and parked in VGPRs while the current chunk is
+//    computed (software pipelining without LDS double buffers) -> LDS slab.
 //  * A sweep is "lane owns a pencil": lane t reads its NIN-long pencil from LDS into registers,
-//    multiplies by the NIN x NOUT basis (wave-uniform operand) and scatters the NOUT results so that
-//    the next sweep's pencils are contiguous again.  Pencil stride in LDS is padded to an odd number of
-//    doubles -> conflict-free ds_read_b64.  Pencils of all EC elements are flattened over the lanes,
-//    so low orders fill the wave (nq=4: 4 elements per wave pass).
-//  * Last sweep: lane <-> (j,i), registers <-> k, so every store instruction writes nq^2 consecutive
-//    doubles of out[e][k][:][:] straight from registers (non-temporal).
-//
-//  * 16-byte stores (even nq): neighbouring lanes (i, i+1) swap one value through DPP so that the even
-//    lane owns out[k][j][i..i+1] and the odd lane out[k+1][j][i-1..i]: each store instruction then writes
-//    two full nq^2 planes with 16 B per lane (measured +5 % over 8-B lanes on the traffic-only shape).
-//  * Chunk -> wave mapping (template KMAP): 0 = persistent, wave w takes chunks w, w+W, ...;
-//    K > 0 = short-lived waves, wave w takes the K consecutive chunks [wK, wK+K).
-//
+//    multiplies by the NIN x NOUT basis and scatters the NOUT results so that the next sweep's pencils
+//    are contiguous again.  Pencil stride in LDS is padded to an odd number of scalars -> conflict-free
+//    reads.  Pencils of all EC elements are flattened over the lanes, so low orders fill the wave.
+//    The input image and both intermediates live one after another in the SAME slab.
+//  * The basis is wave-uniform: BASIS_SMEM fetches it row by row with scalar loads (s_load -> SGPR
+//    operand of the FMA: no LDS traffic, no VGPRs, no barrier to stage it); BASIS_LDS keeps an LDS copy
+//    per workgroup (2D orders whose rows no longer fit the SGPR file).  contract() pins the row-by-row
+//    software pipeline the compiler would otherwise flatten into one spill-heavy block.
+//  * Output (template OUTM).  OUT_ST16 (even nq, fp64): last sweep has lane <-> (j,i), registers <-> k;
+//    neighbouring lanes swap one value through DPP so the even lane owns out[k][j][i..i+1] and the odd lane
+//    out[k+1][j][i-1..i]: every store instruction writes two whole nq^2 planes, 16 B per lane, straight
+//    from registers.  OUT_LDS (any nq, any T): the chunk's output image is assembled in the slab and
+//    leaves as one flat 16-B-per-lane stream -- what odd orders and the 2D kernel need (their direct
+//    stores are fragments).  OUT_ST8: plain per-lane scalar stores (reference point).
 //  * Scalar type: every kernel is a template on T (double = the reference's only instantiation; float =
 //    the T the reference's templates allow but never instantiate).  "16-byte lane" = double2 or float4.
 //
-// Algorithmic HBM traffic per element: sizeof(T)*(nm^d + nq^d) bytes (in read once, out written once).
+// Algorithmic HBM traffic per element: sizeof(T)*(nm^d + nq^d) bytes (in read once, out written once);
+// measured traffic 1.003x that (profiles/hbm_traffic.json).
 #pragma once
 
 #include "sf_common.h"
