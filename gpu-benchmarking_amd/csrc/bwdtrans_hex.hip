@@ -21,9 +21,9 @@ SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 166 / 162
 SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 227 / 223
 SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 247 / 243
 SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 278 / 272
-SF_HEX_CFG(7,  4,   4, BASIS_SMEM, 1, 2, OUT_LDS);  // 268 / 265
+SF_HEX_CFG(7,  4,   2, BASIS_SMEM, 1, 2, OUT_LDS);  // 283 / 275
 SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16); // 295-302 / 287
-SF_HEX_CFG(9,  2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 277 / 274
+SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS);  // 283 / 277
 SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 310 / 306
 #undef SF_HEX_CFG
 
