@@ -40,7 +40,10 @@ template <int NQ, int EC> struct MfmaGeom
     static constexpr int IN_DBL = EC * NMT;
     static constexpr bool VEC2  = (IN_DBL % 2) == 0;
     static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
-    static constexpr int SLAB   = (EC * NM * S + 1) & ~1; // doubles per wave
+    // per-element LDS region: the padded input image; with OUTL it is reused for the element's output
+    // image once step 1 has consumed the input, so it must also hold nq^2 doubles
+    static constexpr int ESTRIDE = ((NM * S > NQT ? NM * S : NQT) + 1) & ~1;
+    static constexpr int SLAB    = EC * ESTRIDE; // doubles per wave
     static_assert(S % 4 == 2 && S >= NM, "row stride");
 };
 
@@ -49,7 +52,7 @@ template <int NQ, int EC, int WPB> constexpr size_t mfma_lds_bytes()
     return sizeof(double) * (size_t)WPB * MfmaGeom<NQ, EC>::SLAB;
 }
 
-// staging registers -> LDS, element e row q at (e*NM + q)*S
+// staging registers -> LDS, element e row q at e*ESTRIDE + q*S
 template <class G>
 __device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double *slab, int lane)
 {
@@ -63,22 +66,23 @@ __device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double
             {
                 const int f0 = 2 * v, f1 = 2 * v + 1;
                 const int r0 = f0 / G::NM, r1 = f1 / G::NM; // flat row index (e*NM + q)
-                slab[r0 * G::S + (f0 - r0 * G::NM)] = st[k].x;
-                slab[r1 * G::S + (f1 - r1 * G::NM)] = st[k].y;
+                const int e0 = r0 / G::NM, e1 = r1 / G::NM;
+                slab[e0 * G::ESTRIDE + (r0 - e0 * G::NM) * G::S + (f0 - r0 * G::NM)] = st[k].x;
+                slab[e1 * G::ESTRIDE + (r1 - e1 * G::NM) * G::S + (f1 - r1 * G::NM)] = st[k].y;
             }
         }
         else
         {
             if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
             {
-                const int r0 = v / G::NM;
-                slab[r0 * G::S + (v - r0 * G::NM)] = st[k].x;
+                const int r0 = v / G::NM, e0 = r0 / G::NM;
+                slab[e0 * G::ESTRIDE + (r0 - e0 * G::NM) * G::S + (v - r0 * G::NM)] = st[k].x;
             }
         }
     }
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 #pragma unroll 1
         for (int e = 0; e < evalid; ++e)
         {
-            const double *img = slab + e * NM * G::S;
+            double *img = slab + e * G::ESTRIDE;
             // ---- step 1: W = In * B0 ------------------------------------------------------------
             double4_t w[G::MT1][G::NT];
 #pragma unroll
@@ -189,17 +193,61 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
             }
             // ---- store: register r of tile (tm, tn) is Out[j = 16tm + g + 4r][i = 16tn + a] -------
             double *oe = out + (c * EC + e) * (uint64_t)G::NQT;
+            if constexpr (OUTL)
+            {
+                // the element's input image is dead (step 1 has read it): assemble the output there
+                // and emit it as one flat 16-B-per-lane stream
+                wave_lds_fence();
 #pragma unroll
-            for (int tm = 0; tm < G::MT2; ++tm)
+                for (int tm = 0; tm < G::MT2; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < G::NT; ++tn)
+                    for (int tn = 0; tn < G::NT; ++tn)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
+                        {
+                            const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
+                            if (j < NQ && i < NQ)
+                                img[j * NQ + i] = o[tm][tn][r];
+                        }
+                wave_lds_fence();
+                constexpr int NST = cdiv(G::NQT / 2, kWave);
+                // element outputs are 16-B aligned when nq^2 is even or the element index is even
+                const bool al16 = ((G::NQT & 1) == 0) || (((c * EC + e) & 1) == 0);
+                if (al16)
+                {
+                    double2_t *oe2 = reinterpret_cast<double2_t *>(oe);
+#pragma unroll
+                    for (int k = 0; k < NST; ++k)
                     {
-                        const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
-                        if (j < NQ && i < NQ)
-                            __builtin_nontemporal_store(o[tm][tn][r], oe + j * NQ + i);
+                        const int v = k * kWave + lane;
+                        if (v < G::NQT / 2)
+                            __builtin_nontemporal_store(*reinterpret_cast<const double2_t *>(img + 2 * v),
+                                                        oe2 + v);
                     }
+                    if ((G::NQT & 1) && lane == 0)
+                        oe[G::NQT - 1] = img[G::NQT - 1];
+                }
+                else
+                {
+                    for (int v = lane; v < G::NQT; v += kWave)
+                        oe[v] = img[v];
+                }
+                wave_lds_fence();
+            }
+            else
+            {
+#pragma unroll
+                for (int tm = 0; tm < G::MT2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < G::NT; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                            const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
+                            if (j < NQ && i < NQ)
+                                __builtin_nontemporal_store(o[tm][tn][r], oe + j * NQ + i);
+                        }
+            }
         }
         wave_lds_fence(); // slab is rewritten by the next chunk's staging
     }

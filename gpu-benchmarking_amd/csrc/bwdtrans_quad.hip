@@ -90,7 +90,7 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
 // order at and above which SF_VARIANT_AUTO prefers the matrix-core kernel
 unsigned quad_mfma_threshold()
 {
-    return 13;
+    return 12; // measured: nq 12 MFMA 346-353 GDOF/s vs wave 331-339 (profiles/r01/tune_quad12_mfma2.log)
 }
 
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

@@ -84,11 +84,11 @@ inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false>
 inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_mfma_kernel<NQ, EC, WPB, MINW, KMAP>;
+    auto kern            = quad_mfma_kernel<NQ, EC, WPB, MINW, KMAP, OUTL>;
     constexpr size_t lds = mfma_lds_bytes<NQ, EC, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)

@@ -9,7 +9,7 @@
 //   1 HIP (thread/elmt)     decomposition of BwdTransQuadKernel        (:15-76)
 //   2 HIP (block/elmt glb)  BwdTransQuadKernel_QP_1D, global wsp       (:302-351)
 //   3 HIP (block/elmt LDS)  BwdTransQuadKernel_QP_1D, shared           (:353-426)
-//   4 HIP (wave/chunk)      flagship (sf_bwdtrans_quad_f64; matrix cores from nq = 13)
+//   4 HIP (wave/chunk)      flagship (sf_bwdtrans_quad_f64; matrix cores from nq = 12)
 //   5 rocBLAS               1 DGEMM + 1 strided-batched DGEMM, global wsp (cuBLAS column :750-836)
 // Extra options AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4), --precision f64|f32

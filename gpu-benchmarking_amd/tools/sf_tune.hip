@@ -105,13 +105,14 @@ void quad_case(const QuadArgs &a)
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT>(a, 0); });
 }
 
-template <int NQ, int EC, int WPB, int MW, int KM> void quad_mfma_case(const QuadArgs &a)
+template <int NQ, int EC, int WPB, int MW, int KM, bool OL = false> void quad_mfma_case(const QuadArgs &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad nq%d MFMA EC%d WPB%d MW%d K%d", NQ, EC, WPB, MW, KM);
+    std::snprintf(label, sizeof label, "quad nq%d MFMA EC%d WPB%d MW%d K%d %s", NQ, EC, WPB, MW, KM,
+                  OL ? "lds" : "st8");
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
-        a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_mfma<NQ, EC, WPB, MW, KM>(a, 0); });
+        a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_mfma<NQ, EC, WPB, MW, KM, OL>(a, 0); });
 }
 
 int main(int argc, char **argv)
@@ -153,7 +154,7 @@ int main(int argc, char **argv)
 #else
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
 #define Q(NQ, EC, WPB, BM, MW, KM, OUT) quad_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
-#define M(NQ, EC, WPB, MW, KM) quad_mfma_case<NQ, EC, WPB, MW, KM>(a);
+#define M(NQ, EC, WPB, MW, KM) quad_mfma_case<NQ, EC, WPB, MW, KM>(a); quad_mfma_case<NQ, EC, WPB, MW, KM, true>(a);
     TUNE_CASES
 #endif
     return 0;
