@@ -63,6 +63,29 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     }
 }
 
+// matrix-core kernel (bwdtrans_mfma.h, hex_mfma_kernel): orders 4..12, chunks of 2 elements
+template <int NQ> static int go_mfma(const HexArgs &a, hipStream_t s)
+{
+    return launch_hex_mfma<NQ, 2, 2, 2, 1>(a, s); // best of the sweep (profiles/r01/tune_hex*_mfma2.log)
+}
+
+int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
+{
+    switch (nq)
+    {
+    case 4: return go_mfma<4>(a, s);
+    case 5: return go_mfma<5>(a, s);
+    case 6: return go_mfma<6>(a, s);
+    case 7: return go_mfma<7>(a, s);
+    case 8: return go_mfma<8>(a, s);
+    case 9: return go_mfma<9>(a, s);
+    case 10: return go_mfma<10>(a, s);
+    case 11: return go_mfma<11>(a, s);
+    case 12: return go_mfma<12>(a, s);
+    default: return SF_ENOTBUILT;
+    }
+}
+
 // fp32 (T = float): same kernels with float4 lanes.  Chunks hold twice the fp64 element count (same
 // bytes), always the LDS-staged flat output (the DPP pair store is the fp64 path).
 template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)

@@ -253,4 +253,244 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
     }
 }
 
+// ================================================================================================
+// 3D hex on the matrix cores (nq <= 16): three chained GEMMs per element, one wavefront per element.
+//
+//   sweep 1  W1[(r,q)][i] = sum_p In[(r,q)][p] * B0[p][i]     A = input rows gathered from LDS, B = B0 regs
+//   sweep 2  W2_r[j][i]   = sum_q B1^T[j][q]   * W1[(r,q)][i] A = B1^T regs, B = sweep-1 accumulators
+//   sweep 3  Out[k][pos]  = sum_r B2^T[k][r]   * W2[r][pos]   A = B2^T regs, B = W2 gathered from LDS
+//
+// Sweep 1 enumerates its rows as R = r*QP + q with the q extent padded to QP = 4*ceil(nm/4): a group of
+// four D rows (register r4 of tile t, lanes g = 0..3) is then four consecutive q of ONE r, i.e. exactly
+// one k-step of sweep 2's B operand -- W1 goes from sweep 1 to sweep 2 without leaving the registers
+// (same trick as the 2D kernel).  Sweep 3 contracts r, which indexes different accumulators, so W2 makes
+// one trip through the element's (dead) LDS image, stored [r][pos = j*nq + i] with a row stride = 16 mod 32
+// doubles (conflict-free B gathers).  The result tile D3 (k on g + 4*reg, 16 consecutive pos on the lanes)
+// is assembled in LDS in final layout and leaves as one flat 16-byte-per-lane stream.
+// Padding (p, q, r, i, j, k beyond nm / nq) always meets a zero basis entry and clamped, finite data.
+// ================================================================================================
+template <int NQ, int EC> struct HexMfmaGeom
+{
+    static constexpr int NM  = NQ - 1;
+    static constexpr int NMT = NM * NM * NM, NQ2 = NQ * NQ, NQT = NQ * NQ * NQ;
+    static constexpr int QP  = (NM + 3) / 4 * 4;        // padded q extent
+    static constexpr int M1  = NM * QP;                 // rows of sweep 1
+    static constexpr int MT1 = cdiv(M1, 16);
+    static constexpr int KS1 = cdiv(NM, 4);             // p steps
+    static constexpr int KS2 = QP / 4;                  // q steps
+    static constexpr int KS3 = cdiv(NM, 4);             // r steps
+    static constexpr int CB  = cdiv(NQ2, 16);           // column blocks of sweep 3
+    static constexpr int S   = NM + ((6 - NM % 4) % 4); // input row stride, S % 4 == 2
+    static constexpr int W2S = (NQ2 + 15) / 32 * 32 + 16; // W2 row stride, = 16 mod 32, >= NQ2
+    static constexpr int IN_DBL = EC * NMT;
+    static constexpr bool VEC2  = (IN_DBL % 2) == 0;
+    static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
+    static constexpr int E0      = NM * NM * S > NM * W2S ? NM * NM * S : NM * W2S;
+    static constexpr int ESTRIDE = ((E0 > NQT ? E0 : NQT) + 1) & ~1; // per-element LDS region
+    static constexpr int SLAB    = EC * ESTRIDE;
+    static_assert(NQ <= 16, "one 16-wide tile per direction");
+    static_assert(S % 4 == 2 && W2S % 32 == 16 && W2S >= NQ2, "LDS strides");
+};
+
+template <int NQ, int EC, int WPB> constexpr size_t hex_mfma_lds_bytes()
+{
+    return sizeof(double) * (size_t)WPB * HexMfmaGeom<NQ, EC>::SLAB;
+}
+
+template <int NQ, int EC, int WPB, int MINW, int KMAP>
+__global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
+    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
+    const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
+{
+    using G          = HexMfmaGeom<NQ, EC>;
+    constexpr int NM = G::NM, QP = G::QP, NQ2 = G::NQ2;
+
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int a = lane & 15, g = lane >> 4;
+    double *slab = lds + wib * G::SLAB;
+
+    const uint64_t nchunk = (nelmt + EC - 1) / EC;
+    const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
+    if (it.count == 0)
+        return;
+
+    // basis operands (zero outside nm x nq)
+    double opB0[G::KS1], opB1[G::KS2], opB2[G::KS3];
+#pragma unroll
+    for (int ks = 0; ks < G::KS1; ++ks)
+    {
+        const int p = ks * 4 + g;
+        opB0[ks]    = (p < NM && a < NQ) ? b0[p * NQ + a] : 0.0; // B[k = p][col = i = a]
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS2; ++ks)
+    {
+        const int q = ks * 4 + g;
+        opB1[ks]    = (q < NM && a < NQ) ? b1[q * NQ + a] : 0.0; // A[row = j = a][k = q]
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS3; ++ks)
+    {
+        const int r = ks * 4 + g;
+        opB2[ks]    = (r < NM && a < NQ) ? b2[r * NQ + a] : 0.0; // A[row = k = a][k = r]
+    }
+    // sweep-1 A gather: row R = 16t + a -> (r, q), clamped into the element
+    int arow[G::MT1];
+#pragma unroll
+    for (int t = 0; t < G::MT1; ++t)
+    {
+        const int R = t * 16 + a;
+        int r = R / QP, q = R - r * QP;
+        r       = r < NM ? r : NM - 1;
+        q       = q < NM ? q : NM - 1;
+        arow[t] = (r * NM + q) * G::S;
+    }
+
+    using GW = WaveGeom<NQ, EC, 3>;
+    static_assert(GW::NLD == G::NLD && GW::IN_DBL == G::IN_DBL, "geometry mismatch");
+    double2_t st[G::NLD];
+    chunk_fetch<GW, EC>(st, in, it.first, nelmt, lane);
+
+    uint64_t c = it.first;
+    for (uint64_t n = 0; n < it.count; ++n, c += it.step)
+    {
+        const uint64_t left = nelmt - c * EC;
+        const int evalid    = left >= EC ? EC : (int)left;
+
+        // staging registers -> LDS: element e, row (r,q) at e*ESTRIDE + (r*NM + q)*S
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            if constexpr (G::VEC2)
+            {
+                if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+                {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                    {
+                        const int f = 2 * v + h, row = f / NM, e = row / (NM * NM);
+                        slab[e * G::ESTRIDE + (row - e * NM * NM) * G::S + (f - row * NM)] = st[k][h];
+                    }
+                }
+            }
+            else
+            {
+                if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
+                {
+                    const int row = v / NM, e = row / (NM * NM);
+                    slab[e * G::ESTRIDE + (row - e * NM * NM) * G::S + (v - row * NM)] = st[k][0];
+                }
+            }
+        }
+        wave_lds_fence();
+        if (n + 1 < it.count)
+            chunk_fetch<GW, EC>(st, in, c + it.step, nelmt, lane);
+
+#pragma unroll 1
+        for (int e = 0; e < evalid; ++e)
+        {
+            double *img = slab + e * G::ESTRIDE;
+            // ---- sweep 1 ------------------------------------------------------------------------
+            double4_t w1[G::MT1];
+#pragma unroll
+            for (int t = 0; t < G::MT1; ++t)
+                w1[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < G::KS1; ++ks)
+            {
+                const int p  = ks * 4 + g;
+                const int pc = p < NM ? p : NM - 1;
+#pragma unroll
+                for (int t = 0; t < G::MT1; ++t)
+                    w1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(img[arow[t] + pc], opB0[ks], w1[t], 0, 0, 0);
+            }
+            // ---- sweep 2: per r, B operand = register (R0 % 16) / 4 of tile R0 / 16, R0 = r*QP + 4*qs
+            double4_t w2[NM];
+#pragma unroll
+            for (int r = 0; r < NM; ++r)
+            {
+                w2[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int qs = 0; qs < G::KS2; ++qs)
+                {
+                    const int R0 = r * QP + 4 * qs;
+                    w2[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB1[qs], w1[R0 / 16][(R0 % 16) / 4],
+                                                                 w2[r], 0, 0, 0);
+                }
+            }
+            // ---- W2 -> LDS [r][pos = j*NQ + i]; lane (g,a), register r4 holds j = g + 4*r4, i = a --------
+            wave_lds_fence(); // every sweep-1 gather of this element has completed
+#pragma unroll
+            for (int r = 0; r < NM; ++r)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                {
+                    const int j = g + 4 * r4;
+                    if (j < NQ && a < NQ)
+                        img[r * G::W2S + j * NQ + a] = w2[r][r4];
+                }
+            wave_lds_fence();
+            // ---- sweep 3 ------------------------------------------------------------------------
+            double4_t o[G::CB];
+#pragma unroll
+            for (int cb = 0; cb < G::CB; ++cb)
+                o[cb] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rs = 0; rs < G::KS3; ++rs)
+            {
+                const int r  = rs * 4 + g;
+                const int rc = r < NM ? r : NM - 1;
+#pragma unroll
+                for (int cb = 0; cb < G::CB; ++cb)
+                {
+                    int pos = cb * 16 + a;
+                    if ((cb + 1) * 16 > NQ2)
+                        pos = pos < NQ2 ? pos : NQ2 - 1;
+                    o[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB2[rs], img[rc * G::W2S + pos], o[cb], 0,
+                                                                 0, 0);
+                }
+            }
+            // ---- Out image in LDS (final layout), then a flat stream --------------------------------------
+            wave_lds_fence(); // all W2 gathers done before the image is overwritten
+#pragma unroll
+            for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                {
+                    const int k = g + 4 * r4, pos = cb * 16 + a;
+                    if (k < NQ && pos < NQ2)
+                        img[k * NQ2 + pos] = o[cb][r4];
+                }
+            wave_lds_fence();
+            double *oe      = out + (c * EC + e) * (uint64_t)G::NQT;
+            const bool al16 = ((G::NQT & 1) == 0) || (((c * EC + e) & 1) == 0);
+            if (al16)
+            {
+                constexpr int NST = cdiv(G::NQT / 2, kWave);
+                double2_t *oe2    = reinterpret_cast<double2_t *>(oe);
+#pragma unroll
+                for (int k = 0; k < NST; ++k)
+                {
+                    const int v = k * kWave + lane;
+                    if (v < G::NQT / 2)
+                        __builtin_nontemporal_store(*reinterpret_cast<const double2_t *>(img + 2 * v),
+                                                    oe2 + v);
+                }
+                if ((G::NQT & 1) && lane == 0)
+                    oe[G::NQT - 1] = img[G::NQT - 1];
+            }
+            else
+            {
+                for (int v = lane; v < G::NQT; v += kWave)
+                    oe[v] = img[v];
+            }
+            wave_lds_fence();
+        }
+        wave_lds_fence(); // slab is rewritten by the next chunk's staging
+    }
+}
+
 } // namespace sf

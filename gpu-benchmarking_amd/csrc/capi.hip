@@ -9,6 +9,7 @@
 namespace sf
 {
 int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
+int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 unsigned quad_mfma_threshold();
@@ -113,6 +114,12 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
         if (!vec_ok)
             return SF_EALIGN;
         return launch_hex_wave_nq(nq0, a, s);
+    case SF_VARIANT_MFMA:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_hex_mfma_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
         return launch_hex_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
     case SF_VARIANT_THREAD:

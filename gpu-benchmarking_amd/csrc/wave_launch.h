@@ -108,4 +108,28 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
+template <int NQ, int EC, int WPB, int MINW, int KMAP>
+inline int launch_hex_mfma(const HexArgs &a, hipStream_t s, int grid_override = 0)
+{
+    static int cache[kMaxDev] = {};
+    auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP>;
+    constexpr size_t lds = hex_mfma_lds_bytes<NQ, EC, WPB>();
+    static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t need   = (nchunk + per - 1) / per;
+    uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
+    if (grid_override > 0)
+        grid = (uint64_t)grid_override;
+    if (grid > need || KMAP > 0)
+        grid = need;
+    if (grid > 0x7fffffffull)
+        return SF_EINVAL;
+    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
 } // namespace sf

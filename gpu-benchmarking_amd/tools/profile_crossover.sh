@@ -2,16 +2,19 @@
 # Counter evidence for the bandwidth -> compute crossover across the order sweep (run ON the GPU box):
 #   for each (benchmark, nq, variant): kernel trace (duration) + three PMC passes
 #   (SQ/GRBM compute counters, FETCH_SIZE, WRITE_SIZE: separate passes, TCC has 4 slots).
-# Usage:  tools/profile_crossover.sh OUTDIR      (then tools/summarize_crossover.py OUTDIR)
+# Usage:  tools/profile_crossover.sh OUTDIR [FILTER]   (then tools/summarize_crossover.py OUTDIR)
+#         FILTER = grep -E pattern on the configuration tags (default: all)
 # The program after `--` is the driver binary itself (no env/bash -c hop under rocprofv3).
 set -u
 here="$(cd "$(dirname "$0")/.." && pwd)"
 out="${1:-gpurun_out/crossover}"
+filter="${2:-.}"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 run() { # tag exe args...
   local tag="$1"; shift
+  echo "$tag" | grep -Eq "$filter" || return 0
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$tag/kt" -- "$@" > "$out/$tag.log" 2>&1 || return 1
   rocprofv3 --pmc $SQ --output-format csv -d "$out/$tag/sq" -- "$@" > /dev/null 2>&1 || return 1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/$tag/fetch" -- "$@" > /dev/null 2>&1 || return 1
@@ -24,6 +27,9 @@ for nq in 2 4 6 8 10; do
 done
 for nq in 8 16 32; do
   run quad_nq${nq}_wave "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant wave || exit 1
+done
+for nq in 8 10; do
+  run hex_nq${nq}_mfma "$here/bin/benchmark05" $nq $nq $nq --nelmt $N --no-baselines --data random --variant mfma || exit 1
 done
 for nq in 16 32; do
   run quad_nq${nq}_mfma "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant mfma || exit 1

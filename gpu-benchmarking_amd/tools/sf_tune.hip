@@ -115,6 +115,15 @@ template <int NQ, int EC, int WPB, int MW, int KM, bool OL = false> void quad_mf
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_mfma<NQ, EC, WPB, MW, KM, OL>(a, 0); });
 }
 
+template <int NQ, int EC, int WPB, int MW, int KM> void hex_mfma_case(const HexArgs &a)
+{
+    char label[96];
+    std::snprintf(label, sizeof label, "hex nq%d MFMA EC%d WPB%d MW%d K%d", NQ, EC, WPB, MW, KM);
+    const double nm = NQ - 1;
+    run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
+        a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma<NQ, EC, WPB, MW, KM>(a, 0); });
+}
+
 int main(int argc, char **argv)
 {
     const int nq       = TUNE_NQ;
@@ -150,6 +159,7 @@ int main(int argc, char **argv)
 #if TUNE_DIM == 3
     HexArgs a{b0, b1, b2, in, nullptr, out, nelmt};
 #define H(NQ, EC, WPB, BM, MW, KM, OUT) hex_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
+#define X(NQ, EC, WPB, MW, KM) hex_mfma_case<NQ, EC, WPB, MW, KM>(a);
     TUNE_CASES
 #else
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
