@@ -147,11 +147,22 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
         it.step  = nwave;
         it.count = gw < nchunk ? (nchunk - gw + nwave - 1) / nwave : 0;
     }
-    else
+    else if constexpr (KMAP > 0)
     {
         it.first = gw * KMAP;
         it.step  = 1;
         it.count = it.first < nchunk ? (nchunk - it.first < KMAP ? nchunk - it.first : KMAP) : 0;
+    }
+    else
+    {
+        // KMAP < 0: the workgroup owns WPB*|KMAP| consecutive chunks and its waves interleave over them
+        // (wave w takes chunks w, w+WPB, ...): at every step the workgroup touches one contiguous span
+        constexpr int K     = -KMAP;
+        const uint64_t base = (uint64_t)blockIdx.x * WPB * K;
+        it.first            = base + wib;
+        it.step             = WPB;
+        const uint64_t end  = base + (uint64_t)WPB * K < nchunk ? base + (uint64_t)WPB * K : nchunk;
+        it.count            = it.first < end ? (end - it.first + WPB - 1) / WPB : 0;
     }
     return it;
 }

@@ -45,12 +45,12 @@ inline int launch_hex_wave(const HexArgsT<T> &a, hipStream_t s, int grid_overrid
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need || KMAP > 0)
+    if (grid > need || KMAP != 0)
         grid = need;
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
@@ -70,12 +70,12 @@ inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need || KMAP > 0)
+    if (grid > need || KMAP != 0)
         grid = need;
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
@@ -94,12 +94,12 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need || KMAP > 0)
+    if (grid > need || KMAP != 0)
         grid = need;
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
@@ -118,12 +118,12 @@ inline int launch_hex_mfma(const HexArgs &a, hipStream_t s, int grid_override = 
     if (a.nelmt == 0)
         return SF_OK;
     const uint64_t nchunk = (a.nelmt + EC - 1) / EC;
-    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : 1);
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
-    if (grid > need || KMAP > 0)
+    if (grid > need || KMAP != 0)
         grid = need;
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
