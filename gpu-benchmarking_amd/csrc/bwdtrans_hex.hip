@@ -63,10 +63,13 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     }
 }
 
-// matrix-core kernel (bwdtrans_mfma.h, hex_mfma_kernel): orders 4..12, chunks of 2 elements
+// matrix-core kernel (bwdtrans_mfma.h, hex_mfma_kernel): orders 4..16, chunks of 2 elements.
+// SF_VARIANT_AUTO uses it above the wave kernel's table (nq 11..16); below, the wave kernel is faster.
 template <int NQ> static int go_mfma(const HexArgs &a, hipStream_t s)
 {
-    return launch_hex_mfma<NQ, 2, 2, 2, 1>(a, s); // best of the sweep (profiles/r01/tune_hex*_mfma2.log)
+    // best of the sweep at nq 8..10 (profiles/r01/tune_hex*_mfma2.log); from nq = 12 the accumulators of the
+    // three sweeps no longer fit 256 registers: one wave per SIMD with the full 512-register file
+    return launch_hex_mfma<NQ, 2, 2, (NQ <= 11 ? 2 : 1), 1>(a, s);
 }
 
 int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
@@ -82,6 +85,10 @@ int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     case 10: return go_mfma<10>(a, s);
     case 11: return go_mfma<11>(a, s);
     case 12: return go_mfma<12>(a, s);
+    case 13: return go_mfma<13>(a, s);
+    case 14: return go_mfma<14>(a, s);
+    case 15: return go_mfma<15>(a, s);
+    case 16: return go_mfma<16>(a, s);
     default: return SF_ENOTBUILT;
     }
 }

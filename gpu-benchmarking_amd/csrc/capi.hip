@@ -103,6 +103,8 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
         if (iso && vec_ok)
         {
             int rc = launch_hex_wave_nq(nq0, a, s);
+            if (rc == SF_ENOTBUILT) // above the wave kernel's table: matrix-core kernel (nq 11..16)
+                rc = launch_hex_mfma_nq(nq0, a, s);
             if (rc != SF_ENOTBUILT)
                 return rc;
         }

@@ -49,7 +49,7 @@ enum
     SF_VARIANT_BLOCK_LDS  = 3, /* one workgroup per element, 3 sweeps in LDS (cf. :291-429)       */
     SF_VARIANT_BLOCK_GLB  = 4, /* one workgroup per element, global workspace (cf. :203-289)       */
     SF_VARIANT_GENERIC    = 5, /* runtime-nq fallback (anisotropic nq0 != nq1 != nq2)              */
-    SF_VARIANT_MFMA       = 6, /* v_mfma_f64_16x16x4 chained GEMMs: 2D quad nq 11..32, 3D hex nq 4..12 */
+    SF_VARIANT_MFMA       = 6, /* v_mfma_f64_16x16x4 chained GEMMs: 2D quad nq 11..32, 3D hex nq 4..16 */
     SF_NUM_VARIANTS       = 7
 };
 

@@ -79,21 +79,25 @@ def test_quad_mfma_parity_all_orders(sf, oracle, nq):
         assert err <= TOL, (nq, nelmt, err)
 
 
-@pytest.mark.parametrize("nq", range(4, 13))
+@pytest.mark.parametrize("nq", range(4, 17))
 def test_hex_mfma_parity_all_orders(sf, oracle, nq):
-    """3D matrix-core kernel: three chained v_mfma_f64_16x16x4 GEMMs, every order it is built for."""
-    for nelmt in (1, 2, 3, 7, 64, 129, 1000):
+    """3D matrix-core kernel: three chained v_mfma_f64_16x16x4 GEMMs, every order it is built for
+    (AUTO routes nq 11..16 to it)."""
+    for nelmt in (1, 2, 3, 7, 64, 129, 600):
         err = _hex_case(sf, oracle, (nq,) * 3, nelmt, "mfma", seed=nelmt + nq)
         assert err <= TOL, (nq, nelmt, err)
+        if nq > 10:
+            err = _hex_case(sf, oracle, (nq,) * 3, nelmt, "auto", seed=nelmt)
+            assert err <= TOL, (nq, nelmt, err)
 
 
 def test_mfma_not_built_cases(sf):
     capi = sf.capi
     b = sf.fill_basis(7, 8)
-    bb = sf.fill_basis(12, 13)
-    x = sf.fill_random(12 ** 3 * 4, 1)
+    bb = sf.fill_basis(16, 17)
+    x = sf.fill_random(16 ** 3 * 4, 1)
     with pytest.raises(capi.SumfactError) as ei:
-        sf.bwdtrans_hex((13, 13, 13), bb, bb, bb, x, variant="mfma")
+        sf.bwdtrans_hex((17, 17, 17), bb, bb, bb, x, variant="mfma")
     assert ei.value.rc == capi.SF_ENOTBUILT
     x2 = sf.fill_random(49 * 4, 1)
     with pytest.raises(capi.SumfactError) as ei:
