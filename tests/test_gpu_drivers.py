@@ -91,6 +91,31 @@ def test_benchmark02_and_03_device_columns(pkg, golden):
             assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
 
 
+def test_bench_contract_single_gpu(pkg):
+    """`python bench.py` (N = 1): one JSON line with the contract keys, the roofline and cpu_baseline
+    objects, the golden-norm self check, and a loose performance floor (reference's best: 26.4)."""
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3",
+                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # exactly ONE line on stdout
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("GDOF/s for 3D hex") and rec["unit"] == "GDOF/s"
+    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["warmup"] == 3
+    assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and rec["dtype"] == "f64"
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    rl = rec["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and rl["unit"] == "GB/s"
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    assert abs(rec["value"] * 19.94169 - rl["achieved"]) / rl["achieved"] < 0.02   # B/DOF consistency
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert rec["golden_norm_check"]["ok"] is True
+    assert set(rec["extra"]["hex_sweep"]) == {str(n) for n in range(2, 11)}
+    assert rec["value"] > 150.0 and rl["frac"] > 0.35   # measured 280-300 / 0.70-0.74
+
+
 def test_bench_two_ranks_rehearsal(pkg, tmp_path):
     """bench.py's N>1 path on real hardware: 2 ranks share the one GPU of this box, scalar reductions
     over gloo (SF_BENCH_BACKEND); checks the contract keys and that the shards add up."""

@@ -376,6 +376,40 @@ def test_hex_linearity_and_idempotence_full_size(sf, torch_mod):
     assert torch_mod.equal(tx, tx2)
 
 
+def test_full_size_elementwise_parity(sf, oracle):
+    """BASELINE configs 1 and 2 at their full size (1 048 576 elements, nq = 8), element by element
+    against the oracle on seeded per-element-distinct data -- not only norms and properties."""
+    nelmt, nq, nm = 1 << 20, 8, 7
+    oracle.set_threads(oracle.usable_cpus())
+    b = [sf.fill_random(nm * nq, 900 + d) for d in range(3)]
+    bh = [_np(v) for v in b]
+    x = sf.fill_random(nelmt * nm ** 3, 4242)
+    out = sf.bwdtrans_hex((nq,) * 3, *b, x)
+    ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *bh, _np(x), form="vector")
+    assert oracle.rel_err(_np(out), ref) <= TOL
+    del out, ref, x
+    x = sf.fill_random(nelmt * nm ** 2, 4243)
+    out = sf.bwdtrans_quad((nq, nq), b[0], b[1], x)
+    ref = oracle.bwdtrans_quad((nq, nq), nelmt, bh[0], bh[1], _np(x))
+    assert oracle.rel_err(_np(out), ref) <= TOL
+
+
+@pytest.mark.parametrize("nq", [2, 3, 4, 5, 6, 7, 9, 10])
+def test_full_size_sampled_parity_hex_sweep(sf, oracle, nq):
+    """BASELINE config 3 (nq sweep at 1 048 576 elements): head, tail and two interior 4096-element
+    windows of the full-size output against the oracle (windows straddle chunk / workgroup seams)."""
+    nelmt, nm = 1 << 20, nq - 1
+    b = [sf.fill_random(nm * nq, 300 + nq + d) for d in range(3)]
+    bh = [_np(v) for v in b]
+    x = sf.fill_random(nelmt * nm ** 3, 5000 + nq)
+    out = sf.bwdtrans_hex((nq,) * 3, *b, x)
+    for lo in (0, 333_333, 777_001, nelmt - 4096):
+        xs = _np(x[lo * nm ** 3:(lo + 4096) * nm ** 3])
+        ref = oracle.bwdtrans_hex((nq,) * 3, 4096, *bh, xs)
+        got = _np(out[lo * nq ** 3:(lo + 4096) * nq ** 3])
+        assert oracle.rel_err(got, ref) <= TOL, (nq, lo)
+
+
 def test_hex_64bit_indexing(sf, oracle, torch_mod):
     """More than 2^32 output doubles (the reference's `unsigned` index overflows above 8 388 608
     elements at nq=8): check the tail elements against the oracle and a checksum identity."""
