@@ -10,7 +10,7 @@
 //   stream_copy              : bandwidth calibrator
 //   vector_add / fill_vecadd : benchmark02 (x += y; benchmark02/benchmark02.cc:16-58, data :84-85)
 //   matvec / fill_matvec     : benchmark03 (y = A x; benchmark03/benchmark03.cc:15-104, data :160-167)
-#include "sf_common.h"
+#include "sf_dispatch.h"
 
 #include <mutex>
 

@@ -12,7 +12,7 @@
 //        SF_VARIANT_THREAD     one thread per element, fused nest, global per-thread scratch (:15-102)
 // Intermediate layouts follow the reference: w1[i][r][q], w2[j][i][r].
 // All element indexing is 64-bit.
-#include "sf_common.h"
+#include "sf_dispatch.h"
 
 namespace sf
 {

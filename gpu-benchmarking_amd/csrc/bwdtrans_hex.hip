@@ -1,6 +1,7 @@
 // bwdtrans_hex.hip -- compile-time instantiations of the 3D hex wave kernel + nq dispatch.
 // One row per isotropic nq; the tuple (EC, WPB, BMODE, MINW) is the tuned configuration
 // (tools/sf_tune prints the sweep these were picked from; DESIGN.md records the numbers).
+#include "sf_dispatch.h"
 #include "wave_launch.h"
 
 namespace sf

@@ -1,5 +1,6 @@
 // bwdtrans_quad.hip -- compile-time instantiations of the 2D quad wave kernel + nq dispatch.
 // (EC, WPB, BMODE, MINW) per nq: tuned configuration, see tools/sf_tune and DESIGN.md.
+#include "sf_dispatch.h"
 #include "wave_launch.h"
 
 namespace sf

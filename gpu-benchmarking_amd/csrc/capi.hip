@@ -1,47 +1,11 @@
 // capi.hip -- the extern "C" boundary of libsumfact.so (declared in include/sumfact.h).
 // Validation + dispatch only; kernels live in bwdtrans_hex.hip / bwdtrans_quad.hip /
 // bwdtrans_generic.hip / aux_kernels.hip.
-#include "sf_common.h"
+#include "sf_dispatch.h"
 
 #include <cstdio>
 #include <cstring>
 
-namespace sf
-{
-int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
-int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s);
-int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
-int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
-unsigned quad_mfma_threshold();
-int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
-                       hipStream_t s);
-int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);
-int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s);
-int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s);
-int fill_sincos(double *in, size_t nelmt, size_t nm_tot, hipStream_t s);
-int fill_basis(double *b, size_t nm, size_t nq, hipStream_t s);
-int fill_random(double *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
-int fill_l2norm(double *x, size_t n, hipStream_t s);
-int stream_copy(const double *src, double *dst, size_t n, hipStream_t s);
-int vector_add(double *x, const double *y, size_t n, hipStream_t s);
-int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
-int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
-int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
-int release_workspaces();
-int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
-int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
-                        hipStream_t s);
-int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s);
-int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s);
-int launch_hex_generic_f32(int variant, unsigned nq0, unsigned nq1, unsigned nq2,
-                           const HexArgsT<float> &a, hipStream_t s);
-int launch_quad_generic_f32(int variant, unsigned nq0, unsigned nq1, const QuadArgsT<float> &a,
-                            hipStream_t s);
-int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s);
-int fill_sincos_f32(float *in, size_t nelmt, size_t nm_tot, hipStream_t s);
-int fill_basis_f32(float *b, size_t nm, size_t nq, hipStream_t s);
-int fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
-} // namespace sf
 
 using namespace sf;
 
