@@ -2,6 +2,7 @@
 // Built once per (TUNE_DIM, TUNE_NQ): sf_tune_hex8, sf_tune_quad8, ...   Usage: sf_tune_X [nelmt] [reps]
 // For every case of tools/tune_cases.h it prints kernel time (hipEvent: min / median / mean over reps),
 // GDOF/s (min and mean), algorithmic GB/s (8*(nm^d+nq^d) B/element) and sqrt(sum out^2) as a sanity value.
+#include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 
 #include <algorithm>
@@ -19,13 +20,6 @@
 #endif
 #include "tune_cases.h"
 
-namespace sf
-{
-int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s);
-int fill_random(double *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
-int fill_basis(double *b, size_t nm, size_t nq, hipStream_t s);
-int stream_copy(const double *src, double *dst, size_t n, hipStream_t s);
-} // namespace sf
 using namespace sf;
 
 #define CK(x)                                                                                      \

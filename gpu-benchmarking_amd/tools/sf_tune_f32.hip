@@ -1,4 +1,5 @@
 // sf_tune_f32.hip -- configuration sweep of the T = float instantiations (development tool).
+#include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 
 #include <algorithm>
@@ -8,12 +9,6 @@
 #include <functional>
 #include <vector>
 
-namespace sf
-{
-int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s);
-int fill_random_f32(float *x, size_t n, uint64_t seed, uint64_t first, hipStream_t s);
-int fill_basis_f32(float *b, size_t nm, size_t nq, hipStream_t s);
-} // namespace sf
 using namespace sf;
 
 #define CK(x)                                                                                      \
