@@ -42,6 +42,7 @@ SYMBOLS = {
     "sf_fill_vecadd_f64": (_i, [_vp, _vp, _sz, _vp]),
     "sf_matvec_f64": (_i, [_u, _u, _vp, _vp, _vp, _vp]),
     "sf_fill_matvec_f64": (_i, [_vp, _vp, _u, _u, _vp]),
+    "sf_set_launch_hint": (_i, [_u, _u]),
     "sf_device_info": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "sf_shutdown": (_i, []),
 }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned n
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void hex_thread_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
+__global__ __launch_bounds__(256) void hex_thread_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
                                                          HexArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned 
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void quad_thread_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a)
+__global__ __launch_bounds__(256) void quad_thread_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *lds = reinterpret_cast<T *>(lds_raw);
@@ -321,6 +321,36 @@ static inline int launch_rc()
 
 constexpr size_t kMaxDynLds = 160 * 1024;
 
+// Launch hints = the reference drivers' `threads` / `elblocks` CLI arguments
+// (benchmark05/benchmark05.cc:1428-1429): block size of the thread-per-element and flat-tid kernels
+// (:1265, :1343) and elements per workgroup of the block-per-element kernels (`blocks = nelmt / elblocks`,
+// :1188).  0 = automatic.  They only shape these reference-style decompositions.
+static unsigned g_hint_threads = 0, g_hint_elblocks = 0;
+
+int set_launch_hint(unsigned threads, unsigned elblocks)
+{
+    g_hint_threads  = threads;
+    g_hint_elblocks = elblocks;
+    return SF_OK;
+}
+
+static inline unsigned hinted_block(unsigned automatic, unsigned work_items)
+{
+    if (g_hint_threads == 0)
+        return automatic;
+    unsigned t = g_hint_threads < work_items ? g_hint_threads : work_items; // min(nq^d, threads), :1343
+    t          = (t + kWave - 1) / kWave * kWave;                           // whole wavefronts
+    return t < 64 ? 64 : (t > 256 ? 256 : t);
+}
+
+static inline unsigned hinted_grid(uint64_t nelmt, uint64_t cap)
+{
+    if (g_hint_elblocks == 0)
+        return (unsigned)(nelmt < cap ? nelmt : cap);
+    const uint64_t g = (nelmt + g_hint_elblocks - 1) / g_hint_elblocks;
+    return (unsigned)(g < 1 ? 1 : (g > 0x7fffffffull ? 0x7fffffffull : g));
+}
+
 template <typename T>
 int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgsT<T> &a,
                          hipStream_t s)
@@ -335,8 +365,9 @@ int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, 
         const size_t lds = sizeof(T) * nbas;
         if (lds > kMaxDynLds)
             return SF_ENOTBUILT;
-        const uint64_t blocks = (a.nelmt + 127) / 128;
-        hex_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
+        const unsigned bs     = hinted_block(128, 0xffffffffu);
+        const uint64_t blocks = (a.nelmt + bs - 1) / bs;
+        hex_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), bs, lds, s>>>(
             nq0, nq1, nq2, a);
         return launch_rc();
     }
@@ -349,9 +380,9 @@ int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, 
     if (lds > kMaxDynLds)
         return SF_ENOTBUILT;
     const unsigned nqt   = nq0 * nq1 * nq2;
-    const unsigned thr   = nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256);
+    const unsigned thr   = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
     const uint64_t cap   = (uint64_t)cu * 32;
-    const unsigned grid  = (unsigned)(a.nelmt < cap ? a.nelmt : cap);
+    const unsigned grid  = hinted_grid(a.nelmt, cap);
     if (glb)
     {
         (void)hipFuncSetAttribute((const void *)hex_block_kernel<true, T>,
@@ -380,8 +411,9 @@ int launch_quad_generic_t(int variant, unsigned nq0, unsigned nq1, const QuadArg
         const size_t lds = sizeof(T) * nbas;
         if (lds > kMaxDynLds)
             return SF_ENOTBUILT;
-        const uint64_t blocks = (a.nelmt + 127) / 128;
-        quad_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), 128, lds, s>>>(
+        const unsigned bs     = hinted_block(128, 0xffffffffu);
+        const uint64_t blocks = (a.nelmt + bs - 1) / bs;
+        quad_thread_kernel<T><<<(unsigned)(blocks > cu * 16 ? cu * 16 : blocks), bs, lds, s>>>(
             nq0, nq1, a);
         return launch_rc();
     }
@@ -394,9 +426,9 @@ int launch_quad_generic_t(int variant, unsigned nq0, unsigned nq1, const QuadArg
     if (lds > kMaxDynLds)
         return SF_ENOTBUILT;
     const unsigned nqt  = nq0 * nq1;
-    const unsigned thr  = nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256);
+    const unsigned thr  = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
     const uint64_t cap  = (uint64_t)cu * 32;
-    const unsigned grid = (unsigned)(a.nelmt < cap ? a.nelmt : cap);
+    const unsigned grid = hinted_grid(a.nelmt, cap);
     if (glb)
     {
         (void)hipFuncSetAttribute((const void *)quad_block_kernel<true, T>,

@@ -362,6 +362,11 @@ int sf_fill_matvec_f64(double *A, double *x, unsigned m, unsigned n, void *strea
     return fill_matvec(A, x, m, n, (hipStream_t)stream);
 }
 
+int sf_set_launch_hint(unsigned threads, unsigned elblocks)
+{
+    return set_launch_hint(threads, elblocks);
+}
+
 int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len)
 {
     int dev      = 0;

@@ -27,6 +27,7 @@ int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
 int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
 int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
 int release_workspaces();
+int set_launch_hint(unsigned threads, unsigned elblocks);
 int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
 int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,
                         hipStream_t s);

@@ -28,8 +28,8 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
               const unsigned int _threads, const unsigned int _elblocks)
 {
     constexpr bool kF32 = std::is_same<T, float>::value; // --precision f32: flagship column only
-    (void)_threads;
-    (void)_elblocks;
+    // threads / elblocks shape the reference-style baseline columns (1-3), as in the reference
+    SF_CHECK(sf_set_launch_hint(_threads, _elblocks));
     const size_t nelmt = size;
     const unsigned nq0 = _nq0, nq1 = _nq1;
     const unsigned nm0 = nq0 - 1u, nm1 = nq1 - 1u;

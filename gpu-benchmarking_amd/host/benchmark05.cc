@@ -14,7 +14,8 @@
 //   5 rocBLAS               1 DGEMM + 2 strided-batched DGEMMs, global wsp (cuBLAS column :1062-1171)
 //   6 HIP (thread/elmt il64) one thread per element on the wave-64 interleaved layout: the `_Coa`
 //                           decomposition (:104-201) without its output-index bug (:193-194)
-// `threads` / `elblocks` are accepted for CLI compatibility; the kernels pick their own launch shapes.
+// `threads` / `elblocks` shape the reference-style baseline columns (block size, elements per workgroup);
+// the flagship kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4), --precision f64|f32
 // (f32 = the T = float instantiation the reference's templates allow: flagship column only).
@@ -32,8 +33,8 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
               const unsigned int _nq2, const unsigned int _threads, const unsigned int _elblocks)
 {
     constexpr bool kF32 = std::is_same<T, float>::value; // --precision f32: flagship column only
-    (void)_threads;
-    (void)_elblocks;
+    // threads / elblocks shape the reference-style baseline columns (1-3), as in the reference
+    SF_CHECK(sf_set_launch_hint(_threads, _elblocks));
     const size_t nelmt = size;
     const unsigned nq0 = _nq0, nq1 = _nq1, nq2 = _nq2;
     const unsigned nm0 = nq0 - 1u, nm1 = nq1 - 1u, nm2 = nq2 - 1u;

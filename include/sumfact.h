@@ -164,6 +164,14 @@ int sf_fill_vecadd_f64(double *x, double *y, size_t n, void *stream);
 int sf_matvec_f64(unsigned m, unsigned n, const double *A, const double *x, double *y, void *stream);
 int sf_fill_matvec_f64(double *A, double *x, unsigned m, unsigned n, void *stream);
 
+/*
+ * The reference drivers' `threads` / `elblocks` arguments (benchmark05/benchmark05.cc:1428-1429): block
+ * size of the thread-per-element / flat-tid kernels and elements per workgroup (`blocks = nelmt/elblocks`,
+ * :1188).  They shape only the reference-style decompositions (SF_VARIANT_THREAD / BLOCK_LDS / BLOCK_GLB);
+ * the wave and matrix-core kernels choose their own launch shapes.  0 = automatic (default).
+ */
+int sf_set_launch_hint(unsigned threads, unsigned elblocks);
+
 /* Number of compute units / device name of the current device (for logs). */
 int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len);
 

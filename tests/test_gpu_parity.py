@@ -332,6 +332,20 @@ def test_fp32_parity(sf, oracle, golden, torch_mod):
     assert abs(norm - want) <= 2e-5 * want
 
 
+def test_launch_hints(sf, oracle):
+    """threads / elblocks (the reference CLI's knobs) change launch shapes of the baseline variants only;
+    results stay correct for every combination."""
+    lib = sf.capi.lib()
+    try:
+        for threads, elblocks in ((64, 1), (128, 1), (256, 4), (1024, 7), (1, 1000)):
+            assert lib.sf_set_launch_hint(threads, elblocks) == 0
+            for variant in ("thread", "block-lds", "block-glb", "auto"):
+                assert _hex_case(sf, oracle, (8, 8, 8), 77, variant) <= TOL
+                assert _quad_case(sf, oracle, (8, 8), 77, variant) <= TOL
+    finally:
+        lib.sf_set_launch_hint(0, 0)
+
+
 def test_empty_and_errors(sf, torch_mod):
     capi = sf.capi
     b = sf.fill_basis(7, 8)
