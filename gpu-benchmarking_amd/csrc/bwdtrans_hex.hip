@@ -3,30 +3,10 @@
 // (tools/sf_tune prints the sweep these were picked from; DESIGN.md records the numbers).
 #include "sf_dispatch.h"
 #include "wave_launch.h"
+#include "wave_table.h"
 
 namespace sf
 {
-
-// NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
-// (0 = persistent), 16-byte stores
-template <int NQ> struct HexCfg;
-#define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_)                                            \
-    template <> struct HexCfg<NQ_>                                                                 \
-    {                                                                                              \
-        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_;                   \
-        static constexpr int OUT = OUT_;                                                           \
-    }
-//          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
-SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16); //  73 /  70
-SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 166 / 162
-SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 227 / 223
-SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 247 / 243
-SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS);  // 278 / 272
-SF_HEX_CFG(7,  4,   2, BASIS_SMEM, 1, 2, OUT_LDS);  // 283 / 275
-SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16); // 295-302 / 287
-SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS);  // 283 / 277
-SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS);  // 310 / 306
-#undef SF_HEX_CFG
 
 // Small batches: with the tuned (fat) chunks a batch of a few thousand elements occupies only a fraction
 // of the 256 CUs, so below ~2 workgroups per CU a fine-grained instantiation is launched instead:
@@ -43,7 +23,7 @@ template <int NQ> static int go(const HexArgs &a, hipStream_t s)
     constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
     if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
         return launch_hex_wave<NQ, HexSmall<NQ>::EC, 1, C::BM, C::MW, 1, HexSmall<NQ>::OUT>(a, s);
-    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
+    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF>(a, s);
 }
 
 // returns SF_ENOTBUILT when nq has no instantiation

@@ -2,35 +2,10 @@
 // (EC, WPB, BMODE, MINW) per nq: tuned configuration, see tools/sf_tune and DESIGN.md.
 #include "sf_dispatch.h"
 #include "wave_launch.h"
+#include "wave_table.h"
 
 namespace sf
 {
-
-template <int NQ> struct QuadCfg;
-#define SF_QUAD_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_)                                           \
-    template <> struct QuadCfg<NQ_>                                                                \
-    {                                                                                              \
-        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_, OUT = OUT_;       \
-    }
-// scalar-operand rows need 2*nq SGPRs each (ring of 3): beyond nq ~ 10 they spill -> LDS copy of the basis
-//           nq  EC  WPB  basis      MINW KMAP out        GDOF/s min/mean @1Mi (profiles/r01/tune_quad*.log)
-SF_QUAD_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_LDS);  // 115 / 112 (9 us kernel: launch-bound)
-SF_QUAD_CFG(3,  42,  4, BASIS_SMEM, 2, 1, OUT_LDS);
-SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 265 / 251
-SF_QUAD_CFG(5,  24,  4, BASIS_SMEM, 2, 1, OUT_LDS);
-SF_QUAD_CFG(6,  10,  4, BASIS_SMEM, 2, 1, OUT_LDS);  // 311 / 304
-SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS);
-SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16); // 336 / 331
-SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS);
-SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS);  // 336 / 329
-SF_QUAD_CFG(11, 10,  4, BASIS_LDS,  1, 1, OUT_LDS);
-SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS);  // 339 / 331
-SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);
-SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);  // 322 / 295
-SF_QUAD_CFG(15, 8,   4, BASIS_LDS,  1, 1, OUT_LDS);
-SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16); // 325 / 302
-SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16); // 118 / 117: VALU-issue-bound (MFMA path: next)
-#undef SF_QUAD_CFG
 
 // small batches: see bwdtrans_hex.hip (HexSmall)
 template <int NQ> struct QuadSmall
@@ -44,7 +19,7 @@ template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
     constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
     if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
         return launch_quad_wave<NQ, QuadSmall<NQ>::EC, 1, C::BM, C::MW, 1, C::OUT>(a, s);
-    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT>(a, s);
+    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF>(a, s);
 }
 
 template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)

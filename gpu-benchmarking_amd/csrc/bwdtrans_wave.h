@@ -114,7 +114,16 @@ template <int NQ, int EC, int DIM, typename T = double> struct WaveGeom
     static constexpr int SLAB_OUT   = (CMax<SLAB0, OUT_DBL>::value + VW - 1) / VW * VW;
     static constexpr int NBAS = (NM * NQ + VW - 1) / VW * VW;
     static constexpr int NLD  = VEC2 ? cdiv(IN_DBL / VW, kWave) : cdiv(IN_DBL, kWave);
+    // the chunk's 16-B lanes can be shifted by up to 7 so that every wave-wide load covers whole 128-B
+    // lines; free when the shifted span needs no extra staging register
+    static constexpr bool ALIGN_OK = VEC2 && cdiv(IN_DBL / VW + 7, kWave) == NLD;
 };
+
+// lanes to skip so that lane 0 of every load instruction sits on a 128-byte line
+__device__ __forceinline__ int align_shift(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p >> 4) & 7));
+}
 
 template <class G, int OUTM> constexpr int slab_doubles()
 {
@@ -170,7 +179,7 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
 // ------------------------------------------------------------------------------------------------
 // chunk load: global -> staging registers (issued one chunk ahead of its use)
 // ------------------------------------------------------------------------------------------------
-template <class G, bool FULL, bool NTL = true>
+template <class G, bool FULL, bool NTL = true, bool AL = false>
 __device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
                                            const typename G::Scalar *__restrict__ src, int lane,
                                            int nvalid /*scalars, only if !FULL*/)
@@ -181,19 +190,23 @@ __device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
     if constexpr (G::VEC2)
     {
         const V *srcv = reinterpret_cast<const V *>(src);
+        const int sh  = AL ? align_shift(src) : 0;
 #pragma unroll
         for (int k = 0; k < G::NLD; ++k)
         {
-            const int v = k * kWave + lane;
+            const int v = k * kWave + lane - sh;
             if constexpr (FULL)
             {
-                if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
+                if (AL ? (v >= 0 && v < G::IN_DBL / VW)
+                       : ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW))
                     st[k] = NTL ? __builtin_nontemporal_load(srcv + v) : srcv[v];
             }
             else
             {
                 V x = {};
-                if (VW * v + VW - 1 < nvalid)
+                if (AL && v < 0)
+                    ;
+                else if (VW * v + VW - 1 < nvalid)
                     x = NTL ? __builtin_nontemporal_load(srcv + v) : srcv[v];
                 else
                 {
@@ -221,9 +234,9 @@ __device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
 }
 
 // staging registers -> LDS slab, pencil stride IN_STRIDE
-template <class G>
+template <class G, bool AL = false>
 __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
-                                            typename G::Scalar *slab, int lane)
+                                            typename G::Scalar *slab, int lane, int sh = 0)
 {
     using V = typename G::Vec;
     constexpr int VW = G::VW;
@@ -232,8 +245,9 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
 #pragma unroll
         for (int k = 0; k < G::NLD; ++k)
         {
-            const int v = k * kWave + lane;
-            if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
+            const int v = k * kWave + lane - (AL ? sh : 0);
+            if (AL ? (v >= 0 && v < G::IN_DBL / VW)
+                   : ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW))
             {
                 if constexpr (G::IN_STRIDE == G::NM)
                 {
@@ -370,16 +384,16 @@ __device__ __forceinline__ T *wave_setup(T *lds, const T *const (&gb)[3], const 
     }
 }
 
-template <class G, int EC, bool NTL = true>
+template <class G, int EC, bool NTL = true, bool AL = false>
 __device__ __forceinline__ void chunk_fetch(typename G::Vec (&st)[G::NLD],
                                             const typename G::Scalar *__restrict__ in, uint64_t c,
                                             uint64_t nelmt, int lane)
 {
     const uint64_t left = nelmt - c * EC;
     if (left >= EC)
-        chunk_load<G, true, NTL>(st, in + c * G::IN_DBL, lane, 0);
+        chunk_load<G, true, NTL, AL>(st, in + c * G::IN_DBL, lane, 0);
     else
-        chunk_load<G, false, NTL>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
+        chunk_load<G, false, NTL, AL>(st, in + c * G::IN_DBL, lane, (int)left * G::NMT);
 }
 
 // Final-sweep store of one pass: lane t owns NOUT values acc[n] destined for dst[n*NSTRIDE]
@@ -422,7 +436,7 @@ __device__ __forceinline__ void store_column(const T (&acc)[NOUT], T *dst, int l
 
 // OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` scalars to HBM
 // with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is a multiple of VW; else scalar lanes).
-template <class G, bool NTS>
+template <class G, bool NTS, bool AL = false>
 __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
                                             typename G::Scalar *__restrict__ dst, int nout, int lane)
 {
@@ -430,12 +444,17 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
     constexpr int VW = G::VW;
     if constexpr (G::OUT_DBL % VW == 0)
     {
-        constexpr int NST = cdiv(G::OUT_DBL / VW, kWave);
+        // AL: lanes shifted so that every wave-wide store covers whole 128-byte lines (one more
+        // instruction at most; matters when the chunk's output is not a multiple of 128 B, i.e. odd nq)
+        constexpr int NST = cdiv(G::OUT_DBL / VW + (AL ? 7 : 0), kWave);
         V *dstv           = reinterpret_cast<V *>(dst);
+        const int sh      = AL ? align_shift(dst) : 0;
 #pragma unroll
         for (int k = 0; k < NST; ++k)
         {
-            const int v = k * kWave + lane;
+            const int v = k * kWave + lane - sh;
+            if (AL && v < 0)
+                continue;
             if (VW * v + VW - 1 < nout)
             {
                 const V x = *reinterpret_cast<const V *>(slab + VW * v);
@@ -499,8 +518,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
     if (it.count == 0)
         return;
 
+    constexpr bool AL = (MEMF & 4) && G::ALIGN_OK;
     typename G::Vec st[G::NLD];
-    chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
+    chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -508,13 +528,13 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        chunk_stage<G>(st, slab, lane);
+        chunk_stage<G, AL>(st, slab, lane, AL ? align_shift(in + c * G::IN_DBL) : 0);
         wave_lds_fence();
 
         // request the next chunk of this wave now; it lands in the staging registers while this
         // chunk is being computed
         if (n + 1 < it.count)
-            chunk_fetch<G, EC, !(MEMF & 1)>(st, in, c + it.step, nelmt, lane);
+            chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);
 
         // ---- direction 0: w1[(e,i,r)][q] = sum_p in[(e,r,q)][p] * B0[p][i] ----------------------
         {
@@ -582,7 +602,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
                     }
                 }
                 wave_lds_fence();
-                chunk_flush<G, !(MEMF & 2)>(slab, oc, evalid * G::NQT, lane);
+                chunk_flush<G, !(MEMF & 2), (MEMF & 8) != 0>(slab, oc, evalid * G::NQT, lane);
             }
             else
             {
@@ -629,8 +649,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
     if (it.count == 0)
         return;
 
+    constexpr bool AL = (MEMF & 4) && G::ALIGN_OK;
     typename G::Vec st[G::NLD];
-    chunk_fetch<G, EC, !(MEMF & 1)>(st, in, it.first, nelmt, lane);
+    chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -638,10 +659,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        chunk_stage<G>(st, slab, lane);
+        chunk_stage<G, AL>(st, slab, lane, AL ? align_shift(in + c * G::IN_DBL) : 0);
         wave_lds_fence();
         if (n + 1 < it.count)
-            chunk_fetch<G, EC, !(MEMF & 1)>(st, in, c + it.step, nelmt, lane);
+            chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);
 
         // ---- direction 0: w[(e,i)][q] = sum_p in[(e,q)][p] * B0[p][i] ---------------------------
         {
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
                     }
                 }
                 wave_lds_fence();
-                chunk_flush<G, !(MEMF & 2)>(slab, oc, evalid * G::NQT, lane);
+                chunk_flush<G, !(MEMF & 2), (MEMF & 8) != 0>(slab, oc, evalid * G::NQT, lane);
             }
             else
             {

@@ -1,0 +1,61 @@
+// wave_table.h -- the tuned configuration of the wave-per-chunk kernels, one row per isotropic nq.
+// Shared by the dispatchers (bwdtrans_hex.hip, bwdtrans_quad.hip) and tools/sf_tune_table.hip, which
+// re-measures every row (and its memory-flag alternatives) on the device.
+#pragma once
+#include "bwdtrans_wave.h"
+
+namespace sf
+{
+
+// MF: memory flags of the kernel (bit 0: plain instead of non-temporal loads, bit 1: plain stores,
+// bit 2: shift the chunk's 16-byte lanes so every wave-wide load covers whole 128-byte lines,
+// bit 3: the same for the OUT_LDS output stream)
+// NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
+// (0 = persistent), 16-byte stores
+template <int NQ> struct HexCfg;
+#define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_, MF_)                                        \
+    template <> struct HexCfg<NQ_>                                                                 \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_;                   \
+        static constexpr int OUT = OUT_, MF = MF_;                                                      \
+    }
+//          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
+SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16, 0); //  73 /  70
+SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
+SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 227 / 223
+SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 247 / 243
+SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 278 / 272
+SF_HEX_CFG(7,  4,   2, BASIS_SMEM, 1, 2, OUT_LDS, 0);  // 283 / 275
+SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16, 4); // 295-302 / 287
+SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS, 8);  // 283 / 277
+SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 310 / 306
+#undef SF_HEX_CFG
+
+template <int NQ> struct QuadCfg;
+#define SF_QUAD_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_, MF_)                                       \
+    template <> struct QuadCfg<NQ_>                                                                \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = WPB_, BM = BM_, MW = MW_, KM = KM_, OUT = OUT_;       \
+        static constexpr int MF = MF_;                                                             \
+    }
+// scalar-operand rows need 2*nq SGPRs each (ring of 3): beyond nq ~ 10 they spill -> LDS copy of the basis
+//           nq  EC  WPB  basis      MINW KMAP out        GDOF/s min/mean @1Mi (profiles/r01/tune_quad*.log)
+SF_QUAD_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 115 / 112 (9 us kernel: launch-bound)
+SF_QUAD_CFG(3,  42,  4, BASIS_SMEM, 2, 1, OUT_LDS, 8);
+SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 265 / 251
+SF_QUAD_CFG(5,  24,  4, BASIS_SMEM, 2, 1, OUT_LDS, 8);
+SF_QUAD_CFG(6,  10,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 311 / 304
+SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
+SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, 0); // 336 / 331
+SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
+SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 336 / 329
+SF_QUAD_CFG(11, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, 12);
+SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 339 / 331
+SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 12);
+SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 322 / 295
+SF_QUAD_CFG(15, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);
+SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16, 0); // 325 / 302
+SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
+#undef SF_QUAD_CFG
+
+} // namespace sf

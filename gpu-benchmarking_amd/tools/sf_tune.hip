@@ -76,16 +76,16 @@ static const char *out_name(int o)
     return o == OUT_ST8 ? "st8 " : (o == OUT_ST16 ? "st16" : "lds ");
 }
 
-template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT, int MEMF = 0>
 void hex_case(const HexArgs &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT));
+    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT), (MEMF & 4) ? " al128" : "");
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
-        [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT>(a, 0); });
+        [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF>(a, 0); });
 }
 
 template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT>
@@ -153,6 +153,7 @@ int main(int argc, char **argv)
 #if TUNE_DIM == 3
     HexArgs a{b0, b1, b2, in, nullptr, out, nelmt};
 #define H(NQ, EC, WPB, BM, MW, KM, OUT) hex_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
+#define HM(NQ, EC, WPB, BM, MW, KM, OUT, MF) hex_case<NQ, EC, WPB, BM, MW, KM, OUT, MF>(a);
 #define X(NQ, EC, WPB, MW, KM) hex_mfma_case<NQ, EC, WPB, MW, KM>(a);
     TUNE_CASES
 #else

@@ -274,6 +274,32 @@ def test_randomised_shapes_and_alignment(sf, oracle, torch_mod):
         assert float(obuf[0 if mis_out else -1]) == 0.0
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_line_alignment_offsets(sf, oracle, torch_mod, dim):
+    """The wave kernels shift their 16-byte lanes so wave-wide loads / stores cover whole 128-byte lines
+    (wave_table.h, MF bits 2 and 3): every 16-byte-multiple offset of `in` and `out` inside a 128-byte line
+    must give the same result, with nothing written before or after the output view."""
+    GUARD = 32
+    for nq in (range(2, 11) if dim == 3 else list(range(2, 17))):
+        nmt, nqt = (nq - 1) ** dim, nq ** dim
+        bs = [sf.fill_random((nq - 1) * nq, 40 + d) for d in range(dim)]
+        for nelmt, off_in, off_out in ((257, 2, 0), (300, 6, 4), (1031, 10, 14), (64, 0, 8), (5, 12, 2)):
+            xbuf = sf.fill_random(nelmt * nmt + 16, 7 * nq + nelmt)
+            x = xbuf[off_in:off_in + nelmt * nmt]
+            obuf = torch_mod.full((nelmt * nqt + 2 * GUARD,), -7.0, dtype=torch_mod.float64, device="cuda")
+            out = obuf[GUARD + off_out - 16:GUARD + off_out - 16 + nelmt * nqt]
+            if dim == 3:
+                sf.bwdtrans_hex((nq,) * 3, *bs, x, out=out, variant="wave")
+                ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *[_np(b) for b in bs], _np(x).copy())
+            else:
+                sf.bwdtrans_quad((nq,) * 2, *bs, x, out=out, variant="wave")
+                ref = oracle.bwdtrans_quad((nq,) * 2, nelmt, *[_np(b) for b in bs], _np(x).copy())
+            assert oracle.rel_err(_np(out), ref) <= TOL, (dim, nq, nelmt, off_in, off_out)
+            head = obuf[:GUARD + off_out - 16]
+            tail = obuf[GUARD + off_out - 16 + nelmt * nqt:]
+            assert bool((head == -7.0).all()) and bool((tail == -7.0).all()), (dim, nq, nelmt)
+
+
 def test_non_default_streams(sf, oracle, torch_mod):
     """`stream` is honoured: two launches on two streams, each synchronised on its own stream."""
     nq, nelmt = 8, 5000
