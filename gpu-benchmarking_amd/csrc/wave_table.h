@@ -25,7 +25,7 @@ SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
 SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 227 / 223
 SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 247 / 243
 SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 278 / 272
-SF_HEX_CFG(7,  4,   2, BASIS_SMEM, 1, 2, OUT_LDS, 0);  // 283 / 275
+SF_HEX_CFG(7,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, 12); // 283 / 279
 SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16, 4); // 295-302 / 287
 SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS, 8);  // 283 / 277
 SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 310 / 306

@@ -81,7 +81,7 @@ void hex_case(const HexArgs &a)
 {
     char label[96];
     std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT), (MEMF & 4) ? " al128" : "");
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT), MEMF == 12 ? " al-io" : (MEMF == 8 ? " al-o" : (MEMF == 4 ? " al-i" : "")));
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
