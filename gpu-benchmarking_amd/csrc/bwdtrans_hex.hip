@@ -78,10 +78,8 @@ int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
 // bytes), always the LDS-staged flat output (the DPP pair store is the fp64 path).
 template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)
 {
-    using C = HexCfg<NQ>;
-    // half the register footprint of fp64 -> twice the waves per SIMD (capped at 4), one chunk per wave
-    constexpr int MW = C::MW >= 2 ? 4 : 2;
-    return launch_hex_wave<NQ, 2 * C::EC, C::WPB, C::BM, MW, 1, OUT_LDS, 0, float>(a, s);
+    using C = HexCfgF32<NQ>;
+    return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
 }
 
 int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s)

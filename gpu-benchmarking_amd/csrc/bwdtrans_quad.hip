@@ -24,9 +24,8 @@ template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
 
 template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
 {
-    using C = QuadCfg<NQ>;
-    constexpr int MW = C::MW >= 2 ? 4 : 2;
-    return launch_quad_wave<NQ, 2 * C::EC, C::WPB, C::BM, MW, 1, OUT_LDS, 0, float>(a, s);
+    using C = QuadCfgF32<NQ>;
+    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
 }
 
 // fp32 (T = float): the vector-ALU kernel for every built order (no fp32 matrix-core variant)

@@ -58,4 +58,26 @@ SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16, 0); // 325 / 302
 SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
 #undef SF_QUAD_CFG
 
+// fp32 rows follow from the fp64 ones: twice the elements per chunk (the same bytes), twice the waves per
+// SIMD (half the register footprint, capped at 4), one chunk per wave, LDS-staged 16-byte output stream.
+// The memory flags are tuned separately (tools/sf_tune_table hexf32 / quadf32).
+constexpr int hex_f32_mf(int nq)
+{
+    return (nq % 2 && nq >= 3) ? 8 : 0; // odd orders: +2..7 % (profiles/r01/tune_table_f32.log)
+}
+constexpr int quad_f32_mf(int nq)
+{
+    return nq == 15 ? 12 : ((nq == 7 || nq == 9 || nq == 11) ? 8 : 0);
+}
+template <int NQ> struct HexCfgF32
+{
+    static constexpr int EC = 2 * HexCfg<NQ>::EC, WPB = HexCfg<NQ>::WPB, BM = HexCfg<NQ>::BM;
+    static constexpr int MW = HexCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = hex_f32_mf(NQ);
+};
+template <int NQ> struct QuadCfgF32
+{
+    static constexpr int EC = 2 * QuadCfg<NQ>::EC, WPB = QuadCfg<NQ>::WPB, BM = QuadCfg<NQ>::BM;
+    static constexpr int MW = QuadCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = quad_f32_mf(NQ);
+};
+
 } // namespace sf

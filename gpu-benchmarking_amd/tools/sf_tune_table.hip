@@ -1,7 +1,7 @@
 // sf_tune_table.hip -- re-measure every row of csrc/wave_table.h on the current device, each with the
 // memory-flag alternatives (bit 2 / bit 3: 128-byte line-aligned chunk loads / output stores), interleaved A/B/A/B so
 // that clock drift shows up as a difference between the two runs of the same variant.
-// Usage: sf_tune_table [nelmt] [reps] [hex|quad|all]
+// Usage: sf_tune_table [nelmt] [reps] [hex|quad|all|hexf32|quadf32]
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 #include "../csrc/wave_table.h"
@@ -100,6 +100,91 @@ template <int NQ, bool OL> static void quad_mfma_one()
         [&]() { return launch_quad_mfma<NQ, 2, 4, 1, (NQ <= 16 ? 1 : 2), OL>(a, 0); });
 }
 
+template <class F> static void run_f32(const char *label, double dof, double bytes, size_t nout, F launch)
+{
+    int rc = launch();
+    CK(hipDeviceSynchronize());
+    if (rc != 0)
+    {
+        std::printf("%-34s rc=%d\n", label, rc);
+        return;
+    }
+    std::vector<double> t;
+    for (int r = 0; r < g_reps; ++r)
+    {
+        CK(hipEventRecord(g_e0, 0));
+        launch();
+        CK(hipEventRecord(g_e1, 0));
+        CK(hipEventSynchronize(g_e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+        t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    double sum = 0;
+    for (double v : t)
+        sum += v;
+    const double tmin = t[0], tmean = sum / t.size();
+    double ss = 0;
+    sumsq_f32_blocking((const float *)g_out, nout, &ss, 0);
+    std::printf("%-34s min %8.4f mean %8.4f ms | %7.2f / %7.2f GDOF/s | %7.1f GB/s (mean) | norm %.7g\n",
+                label, tmin, tmean, dof / (tmin * 1e-3) * 1e-9, dof / (tmean * 1e-3) * 1e-9,
+                bytes / (tmean * 1e-3) * 1e-9, std::sqrt(ss));
+    std::fflush(stdout);
+}
+
+template <int NQ, int MF> static void hex_f32_one()
+{
+    using C = HexCfgF32<NQ>;
+    char label[96];
+    std::snprintf(label, sizeof label, "hex  f32 nq%-2d EC%-3d WPB%d MW%d MF%d", NQ, C::EC, C::WPB, C::MW, MF);
+    const double nm = NQ - 1;
+    const float *b  = (const float *)g_b;
+    HexArgsT<float> a{b, b, b, (const float *)g_in, nullptr, (float *)g_out, g_nelmt};
+    run_f32(label, g_nelmt * nm * nm * nm, g_nelmt * 4.0 * (nm * nm * nm + (double)NQ * NQ * NQ),
+            g_nelmt * (size_t)NQ * NQ * NQ, [&]() {
+                return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF, float>(a, 0);
+            });
+}
+
+template <int NQ, int MF> static void quad_f32_one()
+{
+    using C = QuadCfgF32<NQ>;
+    char label[96];
+    std::snprintf(label, sizeof label, "quad f32 nq%-2d EC%-3d WPB%d MW%d MF%d", NQ, C::EC, C::WPB, C::MW, MF);
+    const double nm = NQ - 1;
+    const float *b  = (const float *)g_b;
+    QuadArgsT<float> a{b, b, (const float *)g_in, nullptr, (float *)g_out, g_nelmt};
+    run_f32(label, g_nelmt * nm * nm, g_nelmt * 4.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
+            [&]() {
+                return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF, float>(a, 0);
+            });
+}
+
+template <int NQ> static void hex_f32_row()
+{
+    fill_basis_f32((float *)g_b, NQ - 1, NQ, 0);
+    CK(hipDeviceSynchronize());
+    hex_f32_one<NQ, 0>();
+    hex_f32_one<NQ, 8>();
+    hex_f32_one<NQ, 12>();
+    hex_f32_one<NQ, 0>();
+    hex_f32_one<NQ, 8>();
+    hex_f32_one<NQ, 12>();
+}
+
+template <int NQ> static void quad_f32_row()
+{
+    fill_basis_f32((float *)g_b, NQ - 1, NQ, 0);
+    CK(hipDeviceSynchronize());
+    quad_f32_one<NQ, 0>();
+    quad_f32_one<NQ, 8>();
+    quad_f32_one<NQ, 12>();
+    quad_f32_one<NQ, 0>();
+    quad_f32_one<NQ, 8>();
+    quad_f32_one<NQ, 12>();
+}
+
 template <int NQ> static void hex_row()
 {
     fill_basis(g_b, NQ - 1, NQ, 0);
@@ -163,6 +248,22 @@ int main(int argc, char **argv)
         quad_row<2>(); quad_row<3>(); quad_row<4>(); quad_row<5>(); quad_row<6>(); quad_row<7>();
         quad_row<8>(); quad_row<9>(); quad_row<10>(); quad_row<11>(); quad_row<12>(); quad_row<13>();
         quad_row<14>(); quad_row<15>(); quad_row<16>(); quad_row<32>();
+    }
+    if (!std::strcmp(which, "hexf32") || !std::strcmp(which, "quadf32"))
+    {
+        fill_random_f32((float *)g_in, nin, 0x5F3759DF, 0, 0);
+        CK(hipDeviceSynchronize());
+    }
+    if (!std::strcmp(which, "hexf32"))
+    {
+        hex_f32_row<2>(); hex_f32_row<3>(); hex_f32_row<4>(); hex_f32_row<5>(); hex_f32_row<6>();
+        hex_f32_row<7>(); hex_f32_row<8>(); hex_f32_row<9>(); hex_f32_row<10>();
+    }
+    if (!std::strcmp(which, "quadf32"))
+    {
+        quad_f32_row<2>(); quad_f32_row<3>(); quad_f32_row<4>(); quad_f32_row<5>(); quad_f32_row<6>();
+        quad_f32_row<7>(); quad_f32_row<8>(); quad_f32_row<9>(); quad_f32_row<10>(); quad_f32_row<11>();
+        quad_f32_row<12>(); quad_f32_row<13>(); quad_f32_row<14>(); quad_f32_row<15>(); quad_f32_row<16>();
     }
     return 0;
 }
