@@ -35,13 +35,13 @@ template <int NQ, int EC> struct MfmaGeom
     static constexpr int NT  = cdiv(NQ, 16); // i tiles
     static constexpr int KS1 = cdiv(NM, 4);  // p steps
     static constexpr int MT2 = cdiv(NQ, 16); // j tiles
-    static constexpr int KS2 = 4 * MT1;      // q steps = rows of step 1's D
+    static constexpr int KS2 = cdiv(NM, 4);  // q steps: groups of four rows of step 1's D that hold a real q
     static constexpr int S   = NM + ((6 - NM % 4) % 4); // row stride, S % 4 == 2
     static constexpr int IN_DBL = EC * NMT;
     static constexpr bool VEC2  = (IN_DBL % 2) == 0;
     static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
-    // per-element LDS region: the padded input image; with OUTL it is reused for the element's output
-    // image once step 1 has consumed the input, so it must also hold nq^2 doubles
+    // per-element LDS region: the padded input image; with OUTL the slab is reused for the chunk's output
+    // image (element e at e*nq^2) once step 1 has consumed the input, so a region also holds nq^2 doubles
     static constexpr int ESTRIDE = ((NM * S > NQT ? NM * S : NQT) + 1) & ~1;
     static constexpr int SLAB    = EC * ESTRIDE; // doubles per wave
     static_assert(S % 4 == 2 && S >= NM, "row stride");
@@ -195,9 +195,11 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
             double *oe = out + (c * EC + e) * (uint64_t)G::NQT;
             if constexpr (OUTL)
             {
-                // the element's input image is dead (step 1 has read it): assemble the output there
-                // and emit it as one flat 16-B-per-lane stream
+                // the element's input image is dead (step 1 has read it): park the output in the slab at
+                // e*nq^2 -- never beyond the start of element e+1's still-live input image, since
+                // ESTRIDE >= nq^2 -- and let the whole chunk leave as one flat stream after the loop
                 wave_lds_fence();
+                double *oimg = slab + e * G::NQT;
 #pragma unroll
                 for (int tm = 0; tm < G::MT2; ++tm)
 #pragma unroll
@@ -207,32 +209,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
                         {
                             const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
                             if (j < NQ && i < NQ)
-                                img[j * NQ + i] = o[tm][tn][r];
+                                oimg[j * NQ + i] = o[tm][tn][r];
                         }
-                wave_lds_fence();
-                constexpr int NST = cdiv(G::NQT / 2, kWave);
-                // element outputs are 16-B aligned when nq^2 is even or the element index is even
-                const bool al16 = ((G::NQT & 1) == 0) || (((c * EC + e) & 1) == 0);
-                if (al16)
-                {
-                    double2_t *oe2 = reinterpret_cast<double2_t *>(oe);
-#pragma unroll
-                    for (int k = 0; k < NST; ++k)
-                    {
-                        const int v = k * kWave + lane;
-                        if (v < G::NQT / 2)
-                            __builtin_nontemporal_store(*reinterpret_cast<const double2_t *>(img + 2 * v),
-                                                        oe2 + v);
-                    }
-                    if ((G::NQT & 1) && lane == 0)
-                        oe[G::NQT - 1] = img[G::NQT - 1];
-                }
-                else
-                {
-                    for (int v = lane; v < G::NQT; v += kWave)
-                        oe[v] = img[v];
-                }
-                wave_lds_fence();
             }
             else
             {
@@ -248,6 +226,12 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
                                 __builtin_nontemporal_store(o[tm][tn][r], oe + j * NQ + i);
                         }
             }
+        }
+        if constexpr (OUTL)
+        {
+            // 16 B per lane, every wave-wide store on whole 128-byte lines (chunk_flush, bwdtrans_wave.h)
+            wave_lds_fence();
+            chunk_flush<GW, true, true>(slab, out + c * (uint64_t)(EC * G::NQT), evalid * G::NQT, lane);
         }
         wave_lds_fence(); // slab is rewritten by the next chunk's staging
     }

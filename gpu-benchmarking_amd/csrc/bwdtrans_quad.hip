@@ -43,9 +43,17 @@ int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t 
 }
 
 // matrix-core kernel (bwdtrans_mfma.h): every order 11..32; chunks of 2 elements
+// Measured per order (profiles/r01/tune_table_quadmfma.log): two waves per SIMD above nq = 16 (the
+// compiler otherwise spends > 256 registers and halves the occupancy); the chunk leaves through LDS as a
+// flat line-aligned stream where direct tile stores would write fragments (rows that are not multiples of
+// 128 B), and straight from the accumulators where rows are whole lines (nq = 16, 24, 32) or short.
+constexpr bool quad_mfma_lds_out(int nq)
+{
+    return nq == 13 || nq == 14 || nq == 15 || nq == 17 || (nq >= 20 && nq <= 23) || (nq >= 25 && nq <= 31);
+}
 template <int NQ> static int go_mfma(const QuadArgs &a, hipStream_t s)
 {
-    return launch_quad_mfma<NQ, 2, 4, 1, (NQ <= 16 ? 1 : 2)>(a, s);
+    return launch_quad_mfma<NQ, 2, 4, (NQ <= 16 ? 1 : 2), (NQ <= 16 ? 1 : 2), quad_mfma_lds_out(NQ)>(a, s);
 }
 
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

@@ -1,7 +1,7 @@
 // sf_tune_table.hip -- re-measure every row of csrc/wave_table.h on the current device, each with the
 // memory-flag alternatives (bit 2 / bit 3: 128-byte line-aligned chunk loads / output stores), interleaved A/B/A/B so
 // that clock drift shows up as a difference between the two runs of the same variant.
-// Usage: sf_tune_table [nelmt] [reps] [hex|quad|all|hexf32|quadf32]
+// Usage: sf_tune_table [nelmt] [reps] [hex|quad|all|hexf32|quadf32|quadmfma]
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 #include "../csrc/wave_table.h"
@@ -90,14 +90,14 @@ template <int NQ, int MF> static void quad_one()
         [&]() { return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF>(a, 0); });
 }
 
-template <int NQ, bool OL> static void quad_mfma_one()
+template <int NQ, bool OL, int MW = 1> static void quad_mfma_one()
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad nq%-2d MFMA EC2 WPB4 %s", NQ, OL ? "lds" : "st8");
+    std::snprintf(label, sizeof label, "quad nq%-2d MFMA EC2 WPB4 MW%d %s", NQ, MW, OL ? "lds" : "st8");
     const double nm = NQ - 1;
     QuadArgs a{g_b, g_b, g_in, nullptr, g_out, g_nelmt};
     run(label, g_nelmt * nm * nm, g_nelmt * 8.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
-        [&]() { return launch_quad_mfma<NQ, 2, 4, 1, (NQ <= 16 ? 1 : 2), OL>(a, 0); });
+        [&]() { return launch_quad_mfma<NQ, 2, 4, MW, (NQ <= 16 ? 1 : 2), OL>(a, 0); });
 }
 
 template <class F> static void run_f32(const char *label, double dof, double bytes, size_t nout, F launch)
@@ -185,6 +185,18 @@ template <int NQ> static void quad_f32_row()
     quad_f32_one<NQ, 12>();
 }
 
+template <int NQ> static void quad_mfma_row()
+{
+    fill_basis(g_b, NQ - 1, NQ, 0);
+    CK(hipDeviceSynchronize());
+    quad_mfma_one<NQ, false, 1>();
+    quad_mfma_one<NQ, true, 1>();
+    quad_mfma_one<NQ, false, 2>();
+    quad_mfma_one<NQ, true, 2>();
+    quad_mfma_one<NQ, false, 3>();
+    quad_mfma_one<NQ, true, 3>();
+}
+
 template <int NQ> static void hex_row()
 {
     fill_basis(g_b, NQ - 1, NQ, 0);
@@ -248,6 +260,15 @@ int main(int argc, char **argv)
         quad_row<2>(); quad_row<3>(); quad_row<4>(); quad_row<5>(); quad_row<6>(); quad_row<7>();
         quad_row<8>(); quad_row<9>(); quad_row<10>(); quad_row<11>(); quad_row<12>(); quad_row<13>();
         quad_row<14>(); quad_row<15>(); quad_row<16>(); quad_row<32>();
+    }
+    if (!std::strcmp(which, "quadmfma"))
+    {
+        quad_mfma_row<11>(); quad_mfma_row<12>(); quad_mfma_row<13>(); quad_mfma_row<14>();
+        quad_mfma_row<15>(); quad_mfma_row<16>(); quad_mfma_row<17>(); quad_mfma_row<18>();
+        quad_mfma_row<19>(); quad_mfma_row<20>(); quad_mfma_row<21>(); quad_mfma_row<22>();
+        quad_mfma_row<23>(); quad_mfma_row<24>(); quad_mfma_row<25>(); quad_mfma_row<26>();
+        quad_mfma_row<27>(); quad_mfma_row<28>(); quad_mfma_row<29>(); quad_mfma_row<30>();
+        quad_mfma_row<31>(); quad_mfma_row<32>();
     }
     if (!std::strcmp(which, "hexf32") || !std::strcmp(which, "quadf32"))
     {
