@@ -44,13 +44,22 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     }
 }
 
-// matrix-core kernel (bwdtrans_mfma.h, hex_mfma_kernel): orders 4..16, chunks of 2 elements.
+// matrix-core kernel (bwdtrans_mfma.h, hex_mfma_kernel): orders 4..16.
 // SF_VARIANT_AUTO uses it above the wave kernel's table (nq 11..16); below, the wave kernel is faster.
 template <int NQ> static int go_mfma(const HexArgs &a, hipStream_t s)
 {
-    // best of the sweep at nq 8..10 (profiles/r01/tune_hex*_mfma2.log); from nq = 12 the accumulators of the
-    // three sweeps no longer fit 256 registers: one wave per SIMD with the full 512-register file
-    return launch_hex_mfma<NQ, 2, 2, (NQ <= 11 ? 2 : 1), 1>(a, s);
+    if constexpr (NQ <= 10)
+        // best of the sweep at nq 8..10 (profiles/r01/tune_hex*_mfma2.log): chunks of 2 elements
+        return launch_hex_mfma<NQ, 2, 2, 2, 1>(a, s);
+    else
+    {
+        // One element's LDS image is 11-32 KB here, so LDS -- not registers -- bounds the residency: one
+        // element per wave and small workgroups keep 5-12 waves per CU in flight (chunks of 2 left 2-3).
+        // profiles/r01/tune_hex1[1-6]_mfma.log: 265 / 313 / 266 / 283 / 252 / 286 GDOF/s at nq = 11..16
+        // (chunks of 2: 212 / 211 / 255 / 132 / 138 / 162).
+        constexpr int WPB = NQ == 11 ? 4 : (NQ <= 13 ? 2 : 1);
+        return launch_hex_mfma<NQ, 1, WPB, 2, 1>(a, s);
+    }
 }
 
 int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
