@@ -128,7 +128,7 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
         if (iso && vec_ok)
         {
             // high order is compute-bound on the vector ALUs: matrix cores first
-            int rc = nq0 >= quad_mfma_threshold() ? launch_quad_mfma_nq(nq0, a, s) : SF_ENOTBUILT;
+            int rc = quad_prefers_mfma(nq0) ? launch_quad_mfma_nq(nq0, a, s) : SF_ENOTBUILT;
             if (rc == SF_ENOTBUILT)
                 rc = launch_quad_wave_nq(nq0, a, s);
             if (rc == SF_ENOTBUILT)

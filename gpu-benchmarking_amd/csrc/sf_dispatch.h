@@ -11,7 +11,7 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
-unsigned quad_mfma_threshold();
+bool quad_prefers_mfma(unsigned nq);
 int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
                        hipStream_t s);
 int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);

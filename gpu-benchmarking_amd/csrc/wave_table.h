@@ -55,6 +55,8 @@ SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 12);
 SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 322 / 295
 SF_QUAD_CFG(15, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);
 SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16, 0); // 325 / 302
+SF_QUAD_CFG(18, 6,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 247 (matrix-core kernel: 207)
+SF_QUAD_CFG(19, 6,   4, BASIS_LDS,  1, 1, OUT_LDS, 12); // 250 (unaligned streams: 172; matrix-core kernel: 233)
 SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
 #undef SF_QUAD_CFG
 
