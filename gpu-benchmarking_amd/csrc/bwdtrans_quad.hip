@@ -36,7 +36,8 @@ int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t 
 #define SF_CASE(N) case N: return go_f32<N>(a, s);
         SF_CASE(2) SF_CASE(3) SF_CASE(4) SF_CASE(5) SF_CASE(6) SF_CASE(7) SF_CASE(8) SF_CASE(9)
         SF_CASE(10) SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16)
-        SF_CASE(18) SF_CASE(19) SF_CASE(32)
+        SF_CASE(17) SF_CASE(18) SF_CASE(19) SF_CASE(20) SF_CASE(21) SF_CASE(22) SF_CASE(23) SF_CASE(24)
+        SF_CASE(32)
 #undef SF_CASE
     default: return SF_ENOTBUILT;
     }
@@ -70,13 +71,14 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
     }
 }
 
-// Orders for which SF_VARIANT_AUTO prefers the matrix-core kernel.  Measured: nq 12 MFMA 346-353 GDOF/s vs
-// wave 331-339 (profiles/r01/tune_quad12_mfma2.log), and the gap grows with the order -- except at nq = 18, 19,
-// where the 16x16x4 tiles are 44 % padding in both directions and the vector-ALU kernel with six elements per
-// chunk is ahead again (247 vs 207 GDOF/s at nq = 18, profiles/r01/tune_quad18_wave.log).
+// Orders for which SF_VARIANT_AUTO prefers the matrix-core kernel: nq 12..16 (346-353 vs 331-339 GDOF/s at
+// nq = 12, profiles/r01/tune_quad12_mfma2.log) and nq 25..32.  In between (17..24) the 16x16x4 tiles are
+// 30-45 % padding in each direction and the vector-ALU kernel with scalar-register basis operands is ahead
+// (306-329 vs 207-282 GDOF/s, profiles/r01/tune_quad*_scol2.log); on MI355X the fp64 matrix and vector pipes
+// have the same peak, so the exact-size FMAs win wherever their operands can be fed.
 bool quad_prefers_mfma(unsigned nq)
 {
-    return nq >= 12 && nq != 18 && nq != 19;
+    return (nq >= 12 && nq <= 16) || nq >= 25;
 }
 
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
@@ -86,7 +88,8 @@ int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
 #define SF_CASE(N) case N: return go<N>(a, s);
         SF_CASE(2) SF_CASE(3) SF_CASE(4) SF_CASE(5) SF_CASE(6) SF_CASE(7) SF_CASE(8) SF_CASE(9)
         SF_CASE(10) SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16)
-        SF_CASE(18) SF_CASE(19) SF_CASE(32)
+        SF_CASE(17) SF_CASE(18) SF_CASE(19) SF_CASE(20) SF_CASE(21) SF_CASE(22) SF_CASE(23) SF_CASE(24)
+        SF_CASE(32)
 #undef SF_CASE
     default: return SF_ENOTBUILT;
     }

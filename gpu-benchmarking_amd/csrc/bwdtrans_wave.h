@@ -54,7 +54,11 @@ enum OutMode
 enum BasisMode
 {
     BASIS_LDS = 0, // broadcast ds_read from the workgroup's LDS copy
-    BASIS_SMEM = 1 // scalar loads (s_load) from global memory -> SGPR operand
+    BASIS_SMEM = 1, // scalar loads (s_load) from global memory -> SGPR operand
+    // the same, but the row is consumed in column blocks of kColBlock scalars so that the operand ring
+    // stays within the SGPR file at high order (a whole row of nq = 32 doubles would need 128 SGPRs)
+    BASIS_SMEM_COLS = 2, // blocks of 8 scalars (one s_load_dwordx16 per row of an fp64 block)
+    BASIS_SMEM_COLS16 = 3 // blocks of 16 scalars
 };
 
 // the 16-byte lane of a scalar type
@@ -283,12 +287,61 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
 }
 
 // ------------------------------------------------------------------------------------------------
+// BASIS_SMEM_COLS: columns [N0, N0+NB) of every basis row through a two-deep SGPR ring, then the next
+// column block (same touch / request / FMA / fence order per row as contract() below)
+// ------------------------------------------------------------------------------------------------
+template <int NIN, int NOUT, int NPASS, int N0, int kColBlock, typename T>
+__device__ __forceinline__ void contract_cols(const T (&u)[NPASS][NIN], T (&acc)[NPASS][NOUT],
+                                              const T *__restrict__ bas, int &zero)
+{
+    constexpr int NB = (NOUT - N0) < kColBlock ? (NOUT - N0) : kColBlock;
+    T b[2][NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        b[0][n] = bas[zero + N0 + n];
+#pragma unroll
+    for (int m = 0; m < NIN; ++m)
+    {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            asm volatile("" : "+s"(zero) : "s"(b[m % 2][n]));
+        if (m + 1 < NIN)
+        {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                b[(m + 1) % 2][n] = bas[zero + (m + 1) * NOUT + N0 + n];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s)
+                acc[s][N0 + n] = (m == 0) ? u[s][0] * b[0][n]
+                                          : fma_t(u[s][m], b[m % 2][n], acc[s][N0 + n]);
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s)
+                asm volatile("" : "+s"(zero) : "v"(acc[s][N0 + n]));
+    }
+    if constexpr (N0 + NB < NOUT)
+        contract_cols<NIN, NOUT, NPASS, N0 + NB, kColBlock, T>(u, acc, bas, zero);
+}
+
+// ------------------------------------------------------------------------------------------------
 // one contraction: acc[pass][n] = sum_m u[pass][m] * B[m*NOUT + n], ascending m, start at 0
 // ------------------------------------------------------------------------------------------------
 template <int NIN, int NOUT, int NPASS, int BMODE, typename T>
 __device__ __forceinline__ void contract(const T (&u)[NPASS][NIN], T (&acc)[NPASS][NOUT],
                                          const T *__restrict__ bas)
 {
+    if constexpr (BMODE == BASIS_SMEM_COLS || BMODE == BASIS_SMEM_COLS16)
+    {
+        int z = 0;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        contract_cols<NIN, NOUT, NPASS, 0, (BMODE == BASIS_SMEM_COLS ? 8 : 16), T>(u, acc, bas, z);
+        return;
+    }
     // The basis is consumed one ROW (fixed m, all n) at a time, with the next row's operands
     // requested before the current row's FMAs and an order fence after them: left alone, hipcc
     // hoists every basis load of the sweep (and of later sweeps) to the top and then spills.

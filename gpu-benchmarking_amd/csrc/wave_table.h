@@ -55,8 +55,16 @@ SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 12);
 SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 322 / 295
 SF_QUAD_CFG(15, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);
 SF_QUAD_CFG(16, 8,   4, BASIS_LDS,  1, 1, OUT_ST16, 0); // 325 / 302
-SF_QUAD_CFG(18, 6,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 247 (matrix-core kernel: 207)
-SF_QUAD_CFG(19, 6,   4, BASIS_LDS,  1, 1, OUT_LDS, 12); // 250 (unaligned streams: 172; matrix-core kernel: 233)
+// nq 17..24: vector-ALU kernel with column-blocked scalar operands (16 columns per SGPR ring): the padded
+// 16x16x4 matrix-core tiles need more pipe cycles here than the exact-size FMAs (profiles/r01/tune_quad*_scol2.log)
+SF_QUAD_CFG(17, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 318 (matrix-core kernel: 282)
+SF_QUAD_CFG(18, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 318 (207)
+SF_QUAD_CFG(19, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 315 (233)
+SF_QUAD_CFG(20, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, 0); // 316 (236)
+SF_QUAD_CFG(21, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 329 (257)
+SF_QUAD_CFG(22, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 308 (247)
+SF_QUAD_CFG(23, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 306 (260)
+SF_QUAD_CFG(24, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, 0); // 282 (270)
 SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
 #undef SF_QUAD_CFG
 

@@ -81,7 +81,7 @@ void hex_case(const HexArgs &a)
 {
     char label[96];
     std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT), MEMF == 12 ? " al-io" : (MEMF == 8 ? " al-o" : (MEMF == 4 ? " al-i" : "")));
+                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM, out_name(OUT), MEMF == 12 ? " al-io" : (MEMF == 8 ? " al-o" : (MEMF == 4 ? " al-i" : "")));
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
@@ -93,7 +93,7 @@ void quad_case(const QuadArgs &a)
 {
     char label[96];
     std::snprintf(label, sizeof label, "quad nq%d EC%d WPB%d %s MW%d K%d %s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, out_name(OUT));
+                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM, out_name(OUT));
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT>(a, 0); });

@@ -259,7 +259,8 @@ int main(int argc, char **argv)
     {
         quad_row<2>(); quad_row<3>(); quad_row<4>(); quad_row<5>(); quad_row<6>(); quad_row<7>();
         quad_row<8>(); quad_row<9>(); quad_row<10>(); quad_row<11>(); quad_row<12>(); quad_row<13>();
-        quad_row<14>(); quad_row<15>(); quad_row<16>(); quad_row<18>(); quad_row<19>(); quad_row<32>();
+        quad_row<14>(); quad_row<15>(); quad_row<16>(); quad_row<17>(); quad_row<18>(); quad_row<19>(); quad_row<20>(); quad_row<21>();
+        quad_row<22>(); quad_row<23>(); quad_row<24>(); quad_row<32>();
     }
     if (!std::strcmp(which, "quadmfma"))
     {
