@@ -54,7 +54,8 @@ constexpr bool quad_mfma_lds_out(int nq)
 }
 template <int NQ> static int go_mfma(const QuadArgs &a, hipStream_t s)
 {
-    return launch_quad_mfma<NQ, 2, 4, (NQ <= 16 ? 1 : 2), (NQ <= 16 ? 1 : 2), quad_mfma_lds_out(NQ)>(a, s);
+    constexpr int EC = (NQ >= 13 && NQ <= 15) ? 4 : 2; // +3 % at nq 13..15 (tune_quad1[3-5]_scol2.log)
+    return launch_quad_mfma<NQ, EC, 4, (NQ <= 16 ? 1 : 2), (NQ <= 16 ? 1 : 2), quad_mfma_lds_out(NQ)>(a, s);
 }
 
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

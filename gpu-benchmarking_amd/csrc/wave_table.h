@@ -49,7 +49,7 @@ SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
 SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, 0); // 336 / 331
 SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
 SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 336 / 329
-SF_QUAD_CFG(11, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, 12);
+SF_QUAD_CFG(11, 10,  4, BASIS_SMEM_COLS, 1, 1, OUT_LDS, 12); // 316 (LDS copy of the basis: 297)
 SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 339 / 331
 SF_QUAD_CFG(13, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 12);
 SF_QUAD_CFG(14, 8,   4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 322 / 295
