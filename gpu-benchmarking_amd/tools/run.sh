@@ -15,7 +15,7 @@ if [ "$what" = hex ] || [ "$what" = all ]; then
   done
 fi
 if [ "$what" = quad ] || [ "$what" = all ]; then
-  for i in 2 4 6 8 10 12 14 16 32; do
+  for i in 2 4 6 8 10 12 14 16 20 24 28 32; do
     echo "quad nq=$i"; "$here/bin/benchmark04" $i $i &> "$out/benchmark04/nq${i}x${i}.log"
   done
 fi
