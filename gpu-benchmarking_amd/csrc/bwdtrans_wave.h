@@ -21,9 +21,13 @@
 //    reads.  Pencils of all EC elements are flattened over the lanes, so low orders fill the wave.
 //    The input image and both intermediates live one after another in the SAME slab.
 //  * The basis is wave-uniform: BASIS_SMEM fetches it row by row with scalar loads (s_load -> SGPR
-//    operand of the FMA: no LDS traffic, no VGPRs, no barrier to stage it); BASIS_LDS keeps an LDS copy
-//    per workgroup (2D orders whose rows no longer fit the SGPR file).  contract() pins the row-by-row
-//    software pipeline the compiler would otherwise flatten into one spill-heavy block.
+//    operand of the FMA: no LDS traffic, no VGPRs, no barrier to stage it); BASIS_SMEM_COLS{,16} do the same
+//    in column blocks of 8 / 16 scalars for rows that no longer fit the SGPR file (2D nq 11, 17..24);
+//    BASIS_LDS keeps an LDS copy per workgroup (reference point: one ds_read per two FMAs).  contract() pins
+//    the row-by-row software pipeline the compiler would otherwise flatten into one spill-heavy block.
+//  * Line alignment (template MEMF bits 2 / 3): the lane -> 16-byte-vector mapping of the chunk load and of the
+//    OUT_LDS output stream is shifted so that every wave-wide instruction covers whole 128-byte lines
+//    (align_shift()); matters for chunks whose byte size is not a multiple of 128 (odd orders: +2-7 %).
 //  * Output (template OUTM).  OUT_ST16 (even nq, fp64): last sweep has lane <-> (j,i), registers <-> k;
 //    neighbouring lanes swap one value through DPP so the even lane owns out[k][j][i..i+1] and the odd lane
 //    out[k+1][j][i-1..i]: every store instruction writes two whole nq^2 planes, 16 B per lane, straight
@@ -55,7 +59,7 @@ enum BasisMode
 {
     BASIS_LDS = 0, // broadcast ds_read from the workgroup's LDS copy
     BASIS_SMEM = 1, // scalar loads (s_load) from global memory -> SGPR operand
-    // the same, but the row is consumed in column blocks of kColBlock scalars so that the operand ring
+    // the same, but the row is consumed in column blocks of 8 / 16 scalars so that the operand ring
     // stays within the SGPR file at high order (a whole row of nq = 32 doubles would need 128 SGPRs)
     BASIS_SMEM_COLS = 2, // blocks of 8 scalars (one s_load_dwordx16 per row of an fp64 block)
     BASIS_SMEM_COLS16 = 3 // blocks of 16 scalars
