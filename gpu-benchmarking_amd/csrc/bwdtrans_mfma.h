@@ -450,27 +450,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                 }
             wave_lds_fence();
             double *oe      = out + (c * EC + e) * (uint64_t)G::NQT;
-            const bool al16 = ((G::NQT & 1) == 0) || (((c * EC + e) & 1) == 0);
-            if (al16)
-            {
-                constexpr int NST = cdiv(G::NQT / 2, kWave);
-                double2_t *oe2    = reinterpret_cast<double2_t *>(oe);
-#pragma unroll
-                for (int k = 0; k < NST; ++k)
-                {
-                    const int v = k * kWave + lane;
-                    if (v < G::NQT / 2)
-                        __builtin_nontemporal_store(*reinterpret_cast<const double2_t *>(img + 2 * v),
-                                                    oe2 + v);
-                }
-                if ((G::NQT & 1) && lane == 0)
-                    oe[G::NQT - 1] = img[G::NQT - 1];
-            }
-            else
-            {
-                for (int v = lane; v < G::NQT; v += kWave)
-                    oe[v] = img[v];
-            }
+            flush_any_f64<G::NQT>(img, oe, G::NQT, lane);
             wave_lds_fence();
         }
         wave_lds_fence(); // slab is rewritten by the next chunk's staging

@@ -547,6 +547,33 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
     }
 }
 
+// Flat fp64 stream LDS -> HBM for a destination that is only 8-byte aligned (odd nq^d, odd element index):
+// lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the destination starts in, so
+// every store is a whole aligned 16-B word and every wave-wide instruction covers whole lines; the at most
+// two half words at the ends are scalar stores.  LDS side: two 8-byte reads per lane (any 8-B alignment).
+template <int NMAX>
+__device__ __forceinline__ void flush_any_f64(const double *img, double *__restrict__ dst, int nout, int lane)
+{
+    const int a    = __builtin_amdgcn_readfirstlane((int)(((uintptr_t)dst >> 3) & 15)); // doubles into the line
+    double2_t *grid = reinterpret_cast<double2_t *>(dst - a);
+    constexpr int NST = cdiv(NMAX + 15, 2 * kWave);
+#pragma unroll
+    for (int k = 0; k < NST; ++k)
+    {
+        const int gv = k * kWave + lane;
+        const int d0 = 2 * gv - a, d1 = d0 + 1;
+        if (d0 >= 0 && d1 < nout)
+        {
+            const double2_t x = {img[d0], img[d1]};
+            __builtin_nontemporal_store(x, grid + gv);
+        }
+        else if (d1 >= 0 && d1 < nout) // d0 == -1: the word straddles the start
+            dst[d1] = img[d1];
+        else if (d0 >= 0 && d0 < nout) // d1 == nout: the word straddles the end
+            dst[d0] = img[d0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3D hex
 // ------------------------------------------------------------------------------------------------
