@@ -335,7 +335,18 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
     using GW = WaveGeom<NQ, EC, 3>;
     static_assert(GW::NLD == G::NLD && GW::IN_DBL == G::IN_DBL, "geometry mismatch");
     double2_t st[G::NLD];
-    chunk_fetch<GW, EC>(st, in, it.first, nelmt, lane);
+    // odd scalars per chunk (one element of an even order): the chunk base is only 8-byte aligned -> word-grid load
+    auto fetch = [&](uint64_t cc) {
+        if constexpr (G::VEC2)
+            chunk_fetch<GW, EC>(st, in, cc, nelmt, lane);
+        else
+        {
+            const uint64_t lft = nelmt - cc * EC;
+            chunk_load_any_f64<G::IN_DBL>(st, in + cc * G::IN_DBL, lane,
+                                          lft >= EC ? G::IN_DBL : (int)lft * G::NMT);
+        }
+    };
+    fetch(it.first);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -360,18 +371,24 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                     }
                 }
             }
-            else
+            else if (k < cdiv(G::IN_DBL + 15, 2 * kWave))
             {
-                if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
+                const int a0 = line_offset_f64(in + c * G::IN_DBL);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
                 {
-                    const int row = v / NM, e = row / (NM * NM);
-                    slab[e * G::ESTRIDE + (row - e * NM * NM) * G::S + (v - row * NM)] = st[k][0];
+                    const int f = 2 * v - a0 + h;
+                    if (f >= 0 && f < G::IN_DBL)
+                    {
+                        const int row = f / NM, e = row / (NM * NM);
+                        slab[e * G::ESTRIDE + (row - e * NM * NM) * G::S + (f - row * NM)] = st[k][h];
+                    }
                 }
             }
         }
         wave_lds_fence();
         if (n + 1 < it.count)
-            chunk_fetch<GW, EC>(st, in, c + it.step, nelmt, lane);
+            fetch(c + it.step);
 
 #pragma unroll 1
         for (int e = 0; e < evalid; ++e)

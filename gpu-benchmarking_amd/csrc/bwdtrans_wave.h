@@ -547,6 +547,39 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
     }
 }
 
+// Chunk load for a source that is only 8-byte aligned (odd scalars per chunk): the mirror image of
+// flush_any_f64 below.  Lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk
+// starts in; st[k] = {src[d0], src[d0 + 1]}, d0 = 2*(k*64 + l) - a, zero outside [0, nvalid).  Every load is a
+// whole aligned 16-B word; the at most two half words at the ends are 8-byte loads.
+__device__ __forceinline__ int line_offset_f64(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p >> 3) & 15)); // doubles into the 128-B line
+}
+
+template <int NMAX, int NREG>
+__device__ __forceinline__ void chunk_load_any_f64(double2_t (&st)[NREG], const double *__restrict__ src,
+                                                   int lane, int nvalid)
+{
+    constexpr int NLDA = cdiv(NMAX + 15, 2 * kWave);
+    static_assert(NLDA <= NREG, "staging registers");
+    const int a           = line_offset_f64(src);
+    const double2_t *grid = reinterpret_cast<const double2_t *>(src - a);
+#pragma unroll
+    for (int k = 0; k < NLDA; ++k)
+    {
+        const int gv = k * kWave + lane;
+        const int d0 = 2 * gv - a, d1 = d0 + 1;
+        double2_t x  = {0.0, 0.0};
+        if (d0 >= 0 && d1 < nvalid)
+            x = __builtin_nontemporal_load(grid + gv);
+        else if (d1 >= 0 && d1 < nvalid)
+            x.y = src[d1];
+        else if (d0 >= 0 && d0 < nvalid)
+            x.x = src[d0];
+        st[k] = x;
+    }
+}
+
 // Flat fp64 stream LDS -> HBM for a destination that is only 8-byte aligned (odd nq^d, odd element index):
 // lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the destination starts in, so
 // every store is a whole aligned 16-B word and every wave-wide instruction covers whole lines; the at most
@@ -554,7 +587,7 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
 template <int NMAX>
 __device__ __forceinline__ void flush_any_f64(const double *img, double *__restrict__ dst, int nout, int lane)
 {
-    const int a    = __builtin_amdgcn_readfirstlane((int)(((uintptr_t)dst >> 3) & 15)); // doubles into the line
+    const int a     = line_offset_f64(dst);
     double2_t *grid = reinterpret_cast<double2_t *>(dst - a);
     constexpr int NST = cdiv(NMAX + 15, 2 * kWave);
 #pragma unroll
