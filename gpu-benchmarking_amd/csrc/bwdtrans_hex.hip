@@ -40,6 +40,7 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     case 8: return go<8>(a, s);
     case 9: return go<9>(a, s);
     case 10: return go<10>(a, s);
+    case 11: return go<11>(a, s);
     default: return SF_ENOTBUILT;
     }
 }
@@ -104,6 +105,7 @@ int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s)
     case 8: return go_f32<8>(a, s);
     case 9: return go_f32<9>(a, s);
     case 10: return go_f32<10>(a, s);
+    case 11: return go_f32<11>(a, s);
     default: return SF_ENOTBUILT;
     }
 }

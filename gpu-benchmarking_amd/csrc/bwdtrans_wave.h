@@ -491,62 +491,6 @@ __device__ __forceinline__ void store_column(const T (&acc)[NOUT], T *dst, int l
     }
 }
 
-// OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` scalars to HBM
-// with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is a multiple of VW; else scalar lanes).
-template <class G, bool NTS, bool AL = false>
-__device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
-                                            typename G::Scalar *__restrict__ dst, int nout, int lane)
-{
-    using V = typename G::Vec;
-    constexpr int VW = G::VW;
-    if constexpr (G::OUT_DBL % VW == 0)
-    {
-        // AL: lanes shifted so that every wave-wide store covers whole 128-byte lines (one more
-        // instruction at most; matters when the chunk's output is not a multiple of 128 B, i.e. odd nq)
-        constexpr int NST = cdiv(G::OUT_DBL / VW + (AL ? 7 : 0), kWave);
-        V *dstv           = reinterpret_cast<V *>(dst);
-        const int sh      = AL ? align_shift(dst) : 0;
-#pragma unroll
-        for (int k = 0; k < NST; ++k)
-        {
-            const int v = k * kWave + lane - sh;
-            if (AL && v < 0)
-                continue;
-            if (VW * v + VW - 1 < nout)
-            {
-                const V x = *reinterpret_cast<const V *>(slab + VW * v);
-                if (NTS)
-                    __builtin_nontemporal_store(x, dstv + v);
-                else
-                    dstv[v] = x;
-            }
-            else
-            {
-#pragma unroll
-                for (int j = 0; j < VW - 1; ++j)
-                    if (VW * v + j < nout)
-                        dst[VW * v + j] = slab[VW * v + j];
-            }
-        }
-    }
-    else
-    {
-        constexpr int NST = cdiv(G::OUT_DBL, kWave);
-#pragma unroll
-        for (int k = 0; k < NST; ++k)
-        {
-            const int v = k * kWave + lane;
-            if (v < nout)
-            {
-                if (NTS)
-                    __builtin_nontemporal_store(slab[v], dst + v);
-                else
-                    dst[v] = slab[v];
-            }
-        }
-    }
-}
-
 // Chunk load for a source that is only 8-byte aligned (odd scalars per chunk): the mirror image of
 // flush_any_f64 below.  Lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk
 // starts in; st[k] = {src[d0], src[d0 + 1]}, d0 = 2*(k*64 + l) - a, zero outside [0, nvalid).  Every load is a
@@ -604,6 +548,67 @@ __device__ __forceinline__ void flush_any_f64(const double *img, double *__restr
             dst[d1] = img[d1];
         else if (d0 >= 0 && d0 < nout) // d1 == nout: the word straddles the end
             dst[d0] = img[d0];
+    }
+}
+
+// OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` scalars to HBM
+// with 16 B per lane (chunk bases are 16-B aligned when OUT_DBL is a multiple of VW; else scalar lanes).
+template <class G, bool NTS, bool AL = false>
+__device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
+                                            typename G::Scalar *__restrict__ dst, int nout, int lane)
+{
+    using V = typename G::Vec;
+    constexpr int VW = G::VW;
+    if constexpr (G::OUT_DBL % VW == 0)
+    {
+        // AL: lanes shifted so that every wave-wide store covers whole 128-byte lines (one more
+        // instruction at most; matters when the chunk's output is not a multiple of 128 B, i.e. odd nq)
+        constexpr int NST = cdiv(G::OUT_DBL / VW + (AL ? 7 : 0), kWave);
+        V *dstv           = reinterpret_cast<V *>(dst);
+        const int sh      = AL ? align_shift(dst) : 0;
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+        {
+            const int v = k * kWave + lane - sh;
+            if (AL && v < 0)
+                continue;
+            if (VW * v + VW - 1 < nout)
+            {
+                const V x = *reinterpret_cast<const V *>(slab + VW * v);
+                if (NTS)
+                    __builtin_nontemporal_store(x, dstv + v);
+                else
+                    dstv[v] = x;
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < VW - 1; ++j)
+                    if (VW * v + j < nout)
+                        dst[VW * v + j] = slab[VW * v + j];
+            }
+        }
+    }
+    else if constexpr (sizeof(typename G::Scalar) == 8)
+    {
+        // odd number of doubles per chunk: every other chunk is only 8-byte aligned
+        flush_any_f64<G::OUT_DBL>(slab, dst, nout, lane);
+    }
+    else
+    {
+        constexpr int NST = cdiv(G::OUT_DBL, kWave);
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+        {
+            const int v = k * kWave + lane;
+            if (v < nout)
+            {
+                if (NTS)
+                    __builtin_nontemporal_store(slab[v], dst + v);
+                else
+                    dst[v] = slab[v];
+            }
+        }
     }
 }
 

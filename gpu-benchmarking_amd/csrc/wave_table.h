@@ -29,6 +29,7 @@ SF_HEX_CFG(7,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, 12); // 283 / 279
 SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16, 4); // 295-302 / 287
 SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS, 8);  // 283 / 277
 SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 310 / 306
+SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
 
 template <int NQ> struct QuadCfg;

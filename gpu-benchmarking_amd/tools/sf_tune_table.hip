@@ -254,6 +254,8 @@ int main(int argc, char **argv)
     {
         hex_row<2>(); hex_row<3>(); hex_row<4>(); hex_row<5>(); hex_row<6>();
         hex_row<7>(); hex_row<8>(); hex_row<9>(); hex_row<10>();
+        if (g_nelmt <= (1u << 19))
+            hex_row<11>();
     }
     if (!std::strcmp(which, "quad") || !std::strcmp(which, "all"))
     {

@@ -55,7 +55,7 @@ def _quad_case(sf, oracle, nq, nelmt, variant, seed=1):
 RAGGED = [1, 2, 3, 5, 13, 14, 15, 63, 64, 65, 127, 257, 1000, 4099]
 
 
-@pytest.mark.parametrize("nq", range(2, 11))
+@pytest.mark.parametrize("nq", range(2, 12))
 def test_hex_wave_parity_all_orders(sf, oracle, nq):
     for nelmt in RAGGED:
         err = _hex_case(sf, oracle, (nq,) * 3, nelmt, "wave", seed=nelmt)
@@ -280,7 +280,7 @@ def test_line_alignment_offsets(sf, oracle, torch_mod, dim):
     (wave_table.h, MF bits 2 and 3): every 16-byte-multiple offset of `in` and `out` inside a 128-byte line
     must give the same result, with nothing written before or after the output view."""
     GUARD = 32
-    for nq in (range(2, 11) if dim == 3 else list(range(2, 25))):
+    for nq in (range(2, 12) if dim == 3 else list(range(2, 25))):
         nmt, nqt = (nq - 1) ** dim, nq ** dim
         bs = [sf.fill_random((nq - 1) * nq, 40 + d) for d in range(dim)]
         for nelmt, off_in, off_out in ((257, 2, 0), (300, 6, 4), (1031, 10, 14), (64, 0, 8), (5, 12, 2)):
@@ -324,7 +324,7 @@ TOL32 = 2e-5   # fp32: eps = 6e-8, sums of up to 3*31 products with cancellation
 def test_fp32_parity(sf, oracle, golden, torch_mod):
     """T = float instantiations: the oracle evaluates the same float inputs in fp64."""
     f32 = torch_mod.float32
-    for nq in list(range(2, 11)) + [(3, 5, 4)]:
+    for nq in list(range(2, 12)) + [(3, 5, 4)]:
         nqs = (nq,) * 3 if isinstance(nq, int) else nq
         nm = [q - 1 for q in nqs]
         for nelmt in (1, 3, 17, 130, 1001):
