@@ -25,9 +25,9 @@ SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
 SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 227 / 223
 SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 247 / 243
 SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 278 / 272
-SF_HEX_CFG(7,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, 12); // 283 / 279
+SF_HEX_CFG(7,  1,   8, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 285 / 283 (one element per wave; output via the word-grid store)
 SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16, 4); // 295-302 / 287
-SF_HEX_CFG(9,  2,   2, BASIS_SMEM, 1, 1, OUT_LDS, 8);  // 283 / 277
+SF_HEX_CFG(9,  1,   2, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 305 / 303
 SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 310 / 306
 SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
@@ -84,6 +84,16 @@ template <int NQ> struct HexCfgF32
 {
     static constexpr int EC = 2 * HexCfg<NQ>::EC, WPB = HexCfg<NQ>::WPB, BM = HexCfg<NQ>::BM;
     static constexpr int MW = HexCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = hex_f32_mf(NQ);
+};
+// nq = 7, 9: the fp64 rows moved to one element per chunk (their odd nq^3 output then leaves through the 8-byte
+// word-grid store, which is fp64-only); fp32 keeps the two-element-based rule (566 / 585 GDOF/s against 492 / 520)
+template <> struct HexCfgF32<7>
+{
+    static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = 8;
+};
+template <> struct HexCfgF32<9>
+{
+    static constexpr int EC = 4, WPB = 2, BM = BASIS_SMEM, MW = 2, KM = 1, OUT = OUT_LDS, MF = 8;
 };
 template <int NQ> struct QuadCfgF32
 {
