@@ -184,6 +184,39 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
     return it;
 }
 
+// Chunk load for a source that is only 8-byte aligned (odd scalars per chunk): the mirror image of
+// flush_any_f64 below.  Lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk
+// starts in; st[k] = {src[d0], src[d0 + 1]}, d0 = 2*(k*64 + l) - a, zero outside [0, nvalid).  Every load is a
+// whole aligned 16-B word; the at most two half words at the ends are 8-byte loads.
+__device__ __forceinline__ int line_offset_f64(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p >> 3) & 15)); // doubles into the 128-B line
+}
+
+template <int NMAX, int NREG>
+__device__ __forceinline__ void chunk_load_any_f64(double2_t (&st)[NREG], const double *__restrict__ src,
+                                                   int lane, int nvalid)
+{
+    constexpr int NLDA = cdiv(NMAX + 15, 2 * kWave);
+    static_assert(NLDA <= NREG, "staging registers");
+    const int a           = line_offset_f64(src);
+    const double2_t *grid = reinterpret_cast<const double2_t *>(src - a);
+#pragma unroll
+    for (int k = 0; k < NLDA; ++k)
+    {
+        const int gv = k * kWave + lane;
+        const int d0 = 2 * gv - a, d1 = d0 + 1;
+        double2_t x  = {0.0, 0.0};
+        if (d0 >= 0 && d1 < nvalid)
+            x = __builtin_nontemporal_load(grid + gv);
+        else if (d1 >= 0 && d1 < nvalid)
+            x.y = src[d1];
+        else if (d0 >= 0 && d0 < nvalid)
+            x.x = src[d0];
+        st[k] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // chunk load: global -> staging registers (issued one chunk ahead of its use)
 // ------------------------------------------------------------------------------------------------
@@ -226,6 +259,11 @@ __device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
                 st[k] = x;
             }
         }
+    }
+    else if constexpr (sizeof(T) == 8)
+    {
+        // odd number of doubles per chunk (every other chunk only 8-byte aligned): 16-byte word-grid load
+        chunk_load_any_f64<G::IN_DBL>(st, src, lane, FULL ? G::IN_DBL : nvalid);
     }
     else
     {
@@ -272,6 +310,25 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
                 }
             }
         }
+    }
+    else if constexpr (sizeof(typename G::Scalar) == 8)
+    {
+        // word-grid registers (chunk_load_any_f64): word k*64 + lane holds scalars 2*(k*64 + lane) - sh + {0, 1},
+        // sh = line_offset_f64(chunk base)
+#pragma unroll
+        for (int k = 0; k < cdiv(G::IN_DBL + 15, 2 * kWave); ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+            {
+                const int f = 2 * (k * kWave + lane) - sh + h;
+                if (f >= 0 && f < G::IN_DBL)
+                {
+                    if constexpr (G::IN_STRIDE == G::NM)
+                        slab[f] = st[k][h];
+                    else
+                        slab[f + f / G::NM] = st[k][h];
+                }
+            }
     }
     else
     {
@@ -491,39 +548,6 @@ __device__ __forceinline__ void store_column(const T (&acc)[NOUT], T *dst, int l
     }
 }
 
-// Chunk load for a source that is only 8-byte aligned (odd scalars per chunk): the mirror image of
-// flush_any_f64 below.  Lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk
-// starts in; st[k] = {src[d0], src[d0 + 1]}, d0 = 2*(k*64 + l) - a, zero outside [0, nvalid).  Every load is a
-// whole aligned 16-B word; the at most two half words at the ends are 8-byte loads.
-__device__ __forceinline__ int line_offset_f64(const void *p)
-{
-    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p >> 3) & 15)); // doubles into the 128-B line
-}
-
-template <int NMAX, int NREG>
-__device__ __forceinline__ void chunk_load_any_f64(double2_t (&st)[NREG], const double *__restrict__ src,
-                                                   int lane, int nvalid)
-{
-    constexpr int NLDA = cdiv(NMAX + 15, 2 * kWave);
-    static_assert(NLDA <= NREG, "staging registers");
-    const int a           = line_offset_f64(src);
-    const double2_t *grid = reinterpret_cast<const double2_t *>(src - a);
-#pragma unroll
-    for (int k = 0; k < NLDA; ++k)
-    {
-        const int gv = k * kWave + lane;
-        const int d0 = 2 * gv - a, d1 = d0 + 1;
-        double2_t x  = {0.0, 0.0};
-        if (d0 >= 0 && d1 < nvalid)
-            x = __builtin_nontemporal_load(grid + gv);
-        else if (d1 >= 0 && d1 < nvalid)
-            x.y = src[d1];
-        else if (d0 >= 0 && d0 < nvalid)
-            x.x = src[d0];
-        st[k] = x;
-    }
-}
-
 // Flat fp64 stream LDS -> HBM for a destination that is only 8-byte aligned (odd nq^d, odd element index):
 // lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the destination starts in, so
 // every store is a whole aligned 16-B word and every wave-wide instruction covers whole lines; the at most
@@ -650,7 +674,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        chunk_stage<G, AL>(st, slab, lane, AL ? align_shift(in + c * G::IN_DBL) : 0);
+        chunk_stage<G, AL>(st, slab, lane,
+                           G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
+                                   : (sizeof(T) == 8 ? line_offset_f64(in + c * G::IN_DBL) : 0));
         wave_lds_fence();
 
         // request the next chunk of this wave now; it lands in the staging registers while this
@@ -781,7 +807,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        chunk_stage<G, AL>(st, slab, lane, AL ? align_shift(in + c * G::IN_DBL) : 0);
+        chunk_stage<G, AL>(st, slab, lane,
+                           G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
+                                   : (sizeof(T) == 8 ? line_offset_f64(in + c * G::IN_DBL) : 0));
         wave_lds_fence();
         if (n + 1 < it.count)
             chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);

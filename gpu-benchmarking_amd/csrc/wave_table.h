@@ -26,9 +26,9 @@ SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 227 / 223
 SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 247 / 243
 SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 278 / 272
 SF_HEX_CFG(7,  1,   8, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 285 / 283 (one element per wave; output via the word-grid store)
-SF_HEX_CFG(8,  4,   4, BASIS_SMEM, 2, 2, OUT_ST16, 4); // 295-302 / 287
+SF_HEX_CFG(8,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 317-320 / 312-314 (four-element chunks, st16: 301-314 / 285-303)
 SF_HEX_CFG(9,  1,   2, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 305 / 303
-SF_HEX_CFG(10, 2,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 310 / 306
+SF_HEX_CFG(10, 1,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 313 / 309 (two-element chunks: 305 / 300)
 SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
 
