@@ -13,7 +13,8 @@ namespace sf
 // quarter-size chunks (kept even: 16-byte alignment of the chunk), one wave per workgroup, one chunk per wave.
 template <int NQ> struct HexSmall
 {
-    static constexpr int EC  = (HexCfg<NQ>::EC / 4 + 1) / 2 * 2 < 2 ? 2 : (HexCfg<NQ>::EC / 4 + 1) / 2 * 2;
+    static constexpr int EC  = HexCfg<NQ>::EC == 1 ? 1
+                               : ((HexCfg<NQ>::EC / 4 + 1) / 2 * 2 < 2 ? 2 : (HexCfg<NQ>::EC / 4 + 1) / 2 * 2);
     static constexpr int OUT = HexCfg<NQ>::OUT;
 };
 
