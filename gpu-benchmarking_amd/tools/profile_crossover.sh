@@ -10,6 +10,7 @@ here="$(cd "$(dirname "$0")/.." && pwd)"
 out="${1:-gpurun_out/crossover}"
 filter="${2:-.}"
 mkdir -p "$out"
+out="$(cd "$out" && pwd)"
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 run() { # tag exe args...
@@ -22,16 +23,21 @@ run() { # tag exe args...
   echo "$tag ok"
 }
 N=1048576
-for nq in 2 4 6 8 10; do
+M=262144   # element count for the 3D orders above 10 (their elements are 20-60 KB)
+for nq in 2 3 4 5 6 7 8 9 10; do
   run hex_nq${nq}_wave "$here/bin/benchmark05" $nq $nq $nq --nelmt $N --no-baselines --data random --variant wave || exit 1
 done
-for nq in 8 16 32; do
+run hex_nq11_wave "$here/bin/benchmark05" 11 11 11 --nelmt $M --no-baselines --data random --variant wave || exit 1
+for nq in 8 16 20 24 32; do
   run quad_nq${nq}_wave "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant wave || exit 1
 done
 for nq in 8 10; do
   run hex_nq${nq}_mfma "$here/bin/benchmark05" $nq $nq $nq --nelmt $N --no-baselines --data random --variant mfma || exit 1
 done
-for nq in 16 32; do
+for nq in 12 14 16; do
+  run hex_nq${nq}_mfma "$here/bin/benchmark05" $nq $nq $nq --nelmt $M --no-baselines --data random --variant mfma || exit 1
+done
+for nq in 12 16 20 24 28 32; do
   run quad_nq${nq}_mfma "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant mfma || exit 1
 done
 echo all-done
