@@ -58,10 +58,10 @@ SF_QUAD_CFG(15, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, 0);  // 334 (283; 359)
 SF_QUAD_CFG(16, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, 0);  // 330 (302; 358)
 // nq 17..24: vector-ALU kernel with column-blocked scalar operands (16 columns per SGPR ring): the padded
 // 16x16x4 matrix-core tiles need more pipe cycles here than the exact-size FMAs (profiles/r01/tune_quad*_scol2.log)
-SF_QUAD_CFG(17, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 318 (matrix-core kernel: 282)
-SF_QUAD_CFG(18, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 318 (207)
-SF_QUAD_CFG(19, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 315 (233)
-SF_QUAD_CFG(20, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, 0); // 316 (236)
+SF_QUAD_CFG(17, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 328 (matrix-core kernel: 282); 3 elements fill 48-51 of the 64 lanes
+SF_QUAD_CFG(18, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 332 (207)
+SF_QUAD_CFG(19, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 334 (233)
+SF_QUAD_CFG(20, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 341 (236); VALU 0.89 busy with 2 elements (38-40 lanes)
 SF_QUAD_CFG(21, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 329 (257)
 SF_QUAD_CFG(22, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 308 (247)
 SF_QUAD_CFG(23, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 306 (260)
