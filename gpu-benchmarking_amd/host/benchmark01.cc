@@ -61,8 +61,9 @@ static double host_sumsq(const double *x, size_t n)
     while (m > 1)
     {
         const size_t h = m / 2;
-#pragma omp parallel for schedule(static) if (h > 4096)
-        for (long long b = 0; b < (long long)h; ++b)
+        // serial on purpose: in place, element b is written while 2b' == b is still to be read by another
+        // iteration -- ascending order is what makes that safe (and the tree is only n / 4096 terms)
+        for (size_t b = 0; b < h; ++b)
             part[b] = part[2 * b] + part[2 * b + 1];
         if (m & 1)
         {

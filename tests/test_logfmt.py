@@ -48,16 +48,18 @@ def test_benchmark01_host_path_log(pkg, golden, tmp_path):
     """BASELINE config 0: benchmark01 host path, no GPU needed: banner, grammar, published norms."""
     exe = os.path.join(BIN, "benchmark01")
     js = tmp_path / "bm01.json"
-    env = dict(os.environ, OMP_NUM_THREADS="4")
-    res = subprocess.run([exe, "--max-size", str(1 << 21), "--json", str(js)], capture_output=True,
+    # up to 2^26 values: beyond 2^25 the leaf sums outnumber 8192 and the reduction tree's upper levels matter
+    # (an earlier version parallelised the in-place tree there and raced)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    res = subprocess.run([exe, "--max-size", str(1 << 26), "--json", str(js)], capture_output=True,
                          text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr
     out = res.stdout
     lines = out.splitlines()
     assert lines[0] == "-" * 32 and lines[1] == "Benchmark01 : L2 norm reduction " and lines[2] == "-" * 32
     log = pkg.logfmt.parse_log(out)
-    assert log.kind == "GB/s" and log.ncols == 2 and len(log.sizes) == 12
-    assert log.sizes[0] == 1024.0 and log.sizes[-1] == float(1 << 21)
+    assert log.kind == "GB/s" and log.ncols == 2 and len(log.sizes) == 17
+    assert log.sizes[0] == 1024.0 and log.sizes[-1] == float(1 << 26)
     # three lines per size
     assert len(lines) == 3 + 3 * len(log.sizes)
     want = {row["n"]: float(row["norm"]) for row in golden["l2norm"]["rows"]}
