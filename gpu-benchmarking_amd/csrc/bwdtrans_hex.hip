@@ -60,7 +60,7 @@ template <int NQ> static int go_mfma(const HexArgs &a, hipStream_t s)
         // profiles/r01/tune_hex1[1-6]_mfma.log: 265 / 313 / 266 / 283 / 252 / 286 GDOF/s at nq = 11..16
         // (chunks of 2: 212 / 211 / 255 / 132 / 138 / 162).
         constexpr int WPB = NQ == 11 ? 4 : (NQ <= 12 ? 2 : 1);
-        return launch_hex_mfma<NQ, 1, WPB, 2, 1>(a, s);
+        return launch_hex_mfma<NQ, 1, WPB, 2, 1, 64>(a, s);
     }
 }
 

@@ -82,7 +82,7 @@ __device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double
     }
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false, int XG = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
     double *slab = lds + wib * G::SLAB;
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
     if (it.count == 0)
         return;
 
@@ -281,7 +281,7 @@ template <int NQ, int EC, int WPB> constexpr size_t hex_mfma_lds_bytes()
     return sizeof(double) * (size_t)WPB * HexMfmaGeom<NQ, EC>::SLAB;
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
     const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
     double *slab = lds + wib * G::SLAB;
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
     if (it.count == 0)
         return;
 

@@ -57,8 +57,9 @@ template <int NQ> static int go_mfma(const QuadArgs &a, hipStream_t s)
     constexpr int EC = (NQ >= 13 && NQ <= 15) ? 4 : 2; // +3 % at nq 13..15 (tune_quad1[3-5]_scol2.log)
     // nq 25..31: two waves per workgroup, one chunk per wave (+3-7 %, profiles/r01/tune_quad2[6-8]_mfma3.log)
     constexpr bool mid = NQ >= 25 && NQ <= 31;
+    // runs of 64 neighbouring workgroups per XCD: +1-3.5 % where the kernel is not compute-bound
     return launch_quad_mfma<NQ, EC, (mid ? 2 : 4), (NQ <= 16 ? 1 : 2), ((NQ <= 16 || mid) ? 1 : 2),
-                            quad_mfma_lds_out(NQ)>(a, s);
+                            quad_mfma_lds_out(NQ), 64>(a, s);
 }
 
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

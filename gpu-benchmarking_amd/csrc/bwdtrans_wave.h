@@ -152,10 +152,29 @@ struct ChunkIter
     uint64_t first, step, count;
 };
 
-template <int KMAP, int WPB>
+// Workgroups are dealt round-robin to the 8 XCDs (one L2 each).  XG > 0 renumbers them so that runs of XG
+// consecutive LOGICAL workgroups -- neighbours in memory -- execute on the same XCD, inside a window of 8*XG
+// workgroups that keeps the DRAM access front as compact as before (the grid must be a multiple of 8*XG or the
+// tail window falls back to the identity).
+template <int XG> __device__ __forceinline__ uint64_t logical_block()
+{
+    const uint64_t b = blockIdx.x;
+    if constexpr (XG <= 0)
+        return b;
+    else
+    {
+        constexpr uint64_t W = 8ull * XG;
+        const uint64_t win = b / W, r = b - win * W;
+        if ((win + 1) * W > gridDim.x)
+            return b; // partial tail window
+        return win * W + (r & 7) * XG + (r >> 3);
+    }
+}
+
+template <int KMAP, int WPB, int XG = 0>
 __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
 {
-    const uint64_t gw = (uint64_t)blockIdx.x * WPB + wib;
+    const uint64_t gw = logical_block<XG>() * WPB + wib;
     ChunkIter it;
     if constexpr (KMAP == 0)
     {
@@ -175,7 +194,7 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
         // KMAP < 0: the workgroup owns WPB*|KMAP| consecutive chunks and its waves interleave over them
         // (wave w takes chunks w, w+WPB, ...): at every step the workgroup touches one contiguous span
         constexpr int K     = -KMAP;
-        const uint64_t base = (uint64_t)blockIdx.x * WPB * K;
+        const uint64_t base = logical_block<XG>() * WPB * K;
         it.first            = base + wib;
         it.step             = WPB;
         const uint64_t end  = base + (uint64_t)WPB * K < nchunk ? base + (uint64_t)WPB * K : nchunk;
@@ -660,7 +679,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
     T *slab = wave_setup<G, 3, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, (MEMF >> 4)>(nchunk, wib);
     if (it.count == 0)
         return;
 
@@ -793,7 +812,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
     T *slab = wave_setup<G, 2, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, (MEMF >> 4)>(nchunk, wib);
     if (it.count == 0)
         return;
 

@@ -84,11 +84,11 @@ inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false, int XG = 0>
 inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_mfma_kernel<NQ, EC, WPB, MINW, KMAP, OUTL>;
+    auto kern            = quad_mfma_kernel<NQ, EC, WPB, MINW, KMAP, OUTL, XG>;
     constexpr size_t lds = mfma_lds_bytes<NQ, EC, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
@@ -108,11 +108,11 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
 inline int launch_hex_mfma(const HexArgs &a, hipStream_t s, int grid_override = 0)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP>;
+    auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP, XG>;
     constexpr size_t lds = hex_mfma_lds_bytes<NQ, EC, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)

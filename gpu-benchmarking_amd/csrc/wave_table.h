@@ -9,9 +9,12 @@ namespace sf
 
 // MF: memory flags of the kernel (bit 0: plain instead of non-temporal loads, bit 1: plain stores,
 // bit 2: shift the chunk's 16-byte lanes so every wave-wide load covers whole 128-byte lines,
-// bit 3: the same for the OUT_LDS output stream)
+// bit 3: the same for the OUT_LDS output stream, bits 4+: XG = MF >> 4, runs of XG neighbouring workgroups per XCD)
 // NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
 // (0 = persistent), 16-byte stores
+// XCD grouping (bwdtrans_wave.h, logical_block()): runs of XG neighbouring workgroups execute on the same XCD
+constexpr int XG16 = 16 << 4, XG64 = 64 << 4;
+
 template <int NQ> struct HexCfg;
 #define SF_HEX_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_, MF_)                                        \
     template <> struct HexCfg<NQ_>                                                                 \
@@ -22,14 +25,14 @@ template <int NQ> struct HexCfg;
 //          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
 SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16, 0); //  73 /  70
 SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
-SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 227 / 223
-SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 247 / 243
-SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 278 / 272
-SF_HEX_CFG(7,  1,   8, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 285 / 283 (one element per wave; output via the word-grid store)
-SF_HEX_CFG(8,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, 0);  // 317-320 / 312-314 (four-element chunks, st16: 301-314 / 285-303)
-SF_HEX_CFG(9,  1,   2, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 305 / 303
-SF_HEX_CFG(10, 1,   4, BASIS_SMEM, 4, 1, OUT_LDS, 8);  // 313 / 309 (two-element chunks: 305 / 300)
-SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 314 (matrix-core kernel: 281); 131 072 elements
+SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 227 / 223
+SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG16 | 8);  // 247 / 243
+SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 278 / 272
+SF_HEX_CFG(7,  1,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 285 / 283 (one element per wave; output via the word-grid store)
+SF_HEX_CFG(8,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 317-320 / 312-314 (four-element chunks, st16: 301-314 / 285-303)
+SF_HEX_CFG(9,  1,   2, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 305 / 303
+SF_HEX_CFG(10, 1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 313 / 309 (two-element chunks: 305 / 300)
+SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
 
 template <int NQ> struct QuadCfg;
@@ -47,25 +50,25 @@ SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 265 / 251
 SF_QUAD_CFG(5,  24,  4, BASIS_SMEM, 2, 1, OUT_LDS, 8);
 SF_QUAD_CFG(6,  10,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 311 / 304
 SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
-SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, 0); // 336 / 331
-SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
-SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, 0);  // 336 / 329
-SF_QUAD_CFG(11, 10,  4, BASIS_SMEM_COLS, 1, 1, OUT_LDS, 12); // 316 (LDS copy of the basis: 297)
-SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, 0);  // 339 / 331
-SF_QUAD_CFG(13, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, 12); // 342 (LDS basis: 287; matrix-core kernel: 349)
-SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, 0);  // 345 (295; 355)
-SF_QUAD_CFG(15, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, 0);  // 334 (283; 359)
-SF_QUAD_CFG(16, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, 0);  // 330 (302; 358)
+SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, XG64); // 336 / 331
+SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 12);
+SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 336 / 329
+SF_QUAD_CFG(11, 10,  4, BASIS_SMEM_COLS, 1, 1, OUT_LDS, XG64 | 12); // 316 (LDS copy of the basis: 297)
+SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, XG64);  // 339 / 331
+SF_QUAD_CFG(13, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64 | 12); // 342 (LDS basis: 287; matrix-core kernel: 349)
+SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);  // 345 (295; 355)
+SF_QUAD_CFG(15, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64);  // 334 (283; 359)
+SF_QUAD_CFG(16, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64);  // 330 (302; 358)
 // nq 17..24: vector-ALU kernel with column-blocked scalar operands (16 columns per SGPR ring): the padded
 // 16x16x4 matrix-core tiles need more pipe cycles here than the exact-size FMAs (profiles/r01/tune_quad*_scol2.log)
-SF_QUAD_CFG(17, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 328 (matrix-core kernel: 282); 3 elements fill 48-51 of the 64 lanes
-SF_QUAD_CFG(18, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 332 (207)
-SF_QUAD_CFG(19, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 334 (233)
-SF_QUAD_CFG(20, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 341 (236); VALU 0.89 busy with 2 elements (38-40 lanes)
-SF_QUAD_CFG(21, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 329 (257)
-SF_QUAD_CFG(22, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  0); // 308 (247)
-SF_QUAD_CFG(23, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  0); // 306 (260)
-SF_QUAD_CFG(24, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, 0); // 282 (270)
+SF_QUAD_CFG(17, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 328 (matrix-core kernel: 282); 3 elements fill 48-51 of the 64 lanes
+SF_QUAD_CFG(18, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 332 (207)
+SF_QUAD_CFG(19, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 334 (233)
+SF_QUAD_CFG(20, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 341 (236); VALU 0.89 busy with 2 elements (38-40 lanes)
+SF_QUAD_CFG(21, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  XG64); // 329 (257)
+SF_QUAD_CFG(22, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 308 (247)
+SF_QUAD_CFG(23, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  XG64); // 306 (260)
+SF_QUAD_CFG(24, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, XG64); // 282 (270)
 SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
 #undef SF_QUAD_CFG
 
@@ -74,11 +77,11 @@ SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue
 // The memory flags are tuned separately (tools/sf_tune_table hexf32 / quadf32).
 constexpr int hex_f32_mf(int nq)
 {
-    return (nq % 2 && nq >= 3) ? 8 : 0; // odd orders: +2..7 % (profiles/r01/tune_table_f32.log)
+    return ((nq % 2 && nq >= 3) ? 8 : 0) | (nq >= 4 ? XG64 : 0); // odd orders: line-aligned output; XCD runs
 }
 constexpr int quad_f32_mf(int nq)
 {
-    return nq == 15 ? 12 : ((nq == 7 || nq == 9 || nq == 11) ? 8 : 0);
+    return (nq == 15 ? 12 : ((nq == 7 || nq == 9 || nq == 11) ? 8 : 0)) | (nq >= 8 ? XG64 : 0);
 }
 template <int NQ> struct HexCfgF32
 {
@@ -89,11 +92,11 @@ template <int NQ> struct HexCfgF32
 // word-grid store, which is fp64-only); fp32 keeps the two-element-based rule (566 / 585 GDOF/s against 492 / 520)
 template <> struct HexCfgF32<7>
 {
-    static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = 8;
+    static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = XG64 | 8;
 };
 template <> struct HexCfgF32<9>
 {
-    static constexpr int EC = 4, WPB = 2, BM = BASIS_SMEM, MW = 2, KM = 1, OUT = OUT_LDS, MF = 8;
+    static constexpr int EC = 4, WPB = 2, BM = BASIS_SMEM, MW = 2, KM = 1, OUT = OUT_LDS, MF = XG64 | 8;
 };
 template <int NQ> struct QuadCfgF32
 {

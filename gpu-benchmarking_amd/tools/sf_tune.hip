@@ -80,8 +80,13 @@ template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT, int MEMF = 0
 void hex_case(const HexArgs &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM, out_name(OUT), MEMF == 12 ? " al-io" : (MEMF == 8 ? " al-o" : (MEMF == 4 ? " al-i" : "")));
+    char xg[16] = "";
+    if (MEMF >= 16)
+        std::snprintf(xg, sizeof xg, " xg%d", MEMF >> 4);
+    std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s%s", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")),
+                  MW, KM, out_name(OUT),
+                  (MEMF & 12) == 12 ? " al-io" : ((MEMF & 12) == 8 ? " al-o" : ((MEMF & 12) == 4 ? " al-i" : "")), xg);
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,

@@ -1,5 +1,5 @@
 // sf_tune_table.hip -- re-measure every row of csrc/wave_table.h on the current device, each with the
-// memory-flag alternatives (bit 2 / bit 3: 128-byte line-aligned chunk loads / output stores), interleaved A/B/A/B so
+// XCD-grouping alternatives (MF bits 4+: runs of 16 / 64 neighbouring workgroups per XCD), interleaved A/B/A/B so
 // that clock drift shows up as a difference between the two runs of the same variant.
 // Usage: sf_tune_table [nelmt] [reps] [hex|quad|all|hexf32|quadf32|quadmfma]
 #include "../csrc/sf_dispatch.h"
@@ -90,14 +90,14 @@ template <int NQ, int MF> static void quad_one()
         [&]() { return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF>(a, 0); });
 }
 
-template <int NQ, bool OL, int MW = 1> static void quad_mfma_one()
+template <int NQ, bool OL, int MW = 1, int XG = 0> static void quad_mfma_one()
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad nq%-2d MFMA EC2 WPB4 MW%d %s", NQ, MW, OL ? "lds" : "st8");
+    std::snprintf(label, sizeof label, "quad nq%-2d MFMA EC2 WPB4 MW%d %s xg%d", NQ, MW, OL ? "lds" : "st8", XG);
     const double nm = NQ - 1;
     QuadArgs a{g_b, g_b, g_in, nullptr, g_out, g_nelmt};
     run(label, g_nelmt * nm * nm, g_nelmt * 8.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
-        [&]() { return launch_quad_mfma<NQ, 2, 4, MW, (NQ <= 16 ? 1 : 2), OL>(a, 0); });
+        [&]() { return launch_quad_mfma<NQ, 2, 4, MW, (NQ <= 16 ? 1 : 2), OL, XG>(a, 0); });
 }
 
 template <class F> static void run_f32(const char *label, double dof, double bytes, size_t nout, F launch)
@@ -165,36 +165,41 @@ template <int NQ> static void hex_f32_row()
 {
     fill_basis_f32((float *)g_b, NQ - 1, NQ, 0);
     CK(hipDeviceSynchronize());
-    hex_f32_one<NQ, 0>();
-    hex_f32_one<NQ, 8>();
-    hex_f32_one<NQ, 12>();
-    hex_f32_one<NQ, 0>();
-    hex_f32_one<NQ, 8>();
-    hex_f32_one<NQ, 12>();
+    constexpr int B = HexCfgF32<NQ>::MF & 15;
+    hex_f32_one<NQ, B>();
+    hex_f32_one<NQ, B | (16 << 4)>();
+    hex_f32_one<NQ, B | (64 << 4)>();
+    hex_f32_one<NQ, B>();
+    hex_f32_one<NQ, B | (16 << 4)>();
+    hex_f32_one<NQ, B | (64 << 4)>();
 }
 
 template <int NQ> static void quad_f32_row()
 {
     fill_basis_f32((float *)g_b, NQ - 1, NQ, 0);
     CK(hipDeviceSynchronize());
-    quad_f32_one<NQ, 0>();
-    quad_f32_one<NQ, 8>();
-    quad_f32_one<NQ, 12>();
-    quad_f32_one<NQ, 0>();
-    quad_f32_one<NQ, 8>();
-    quad_f32_one<NQ, 12>();
+    constexpr int B = QuadCfgF32<NQ>::MF & 15;
+    quad_f32_one<NQ, B>();
+    quad_f32_one<NQ, B | (16 << 4)>();
+    quad_f32_one<NQ, B | (64 << 4)>();
+    quad_f32_one<NQ, B>();
+    quad_f32_one<NQ, B | (16 << 4)>();
+    quad_f32_one<NQ, B | (64 << 4)>();
 }
 
 template <int NQ> static void quad_mfma_row()
 {
     fill_basis(g_b, NQ - 1, NQ, 0);
     CK(hipDeviceSynchronize());
-    quad_mfma_one<NQ, false, 1>();
-    quad_mfma_one<NQ, true, 1>();
-    quad_mfma_one<NQ, false, 2>();
-    quad_mfma_one<NQ, true, 2>();
-    quad_mfma_one<NQ, false, 3>();
-    quad_mfma_one<NQ, true, 3>();
+    constexpr int MW = NQ <= 16 ? 1 : 2;
+    quad_mfma_one<NQ, false, MW, 0>();
+    quad_mfma_one<NQ, false, MW, 64>();
+    quad_mfma_one<NQ, true, MW, 0>();
+    quad_mfma_one<NQ, true, MW, 64>();
+    quad_mfma_one<NQ, false, MW, 0>();
+    quad_mfma_one<NQ, false, MW, 64>();
+    quad_mfma_one<NQ, true, MW, 0>();
+    quad_mfma_one<NQ, true, MW, 64>();
 }
 
 template <int NQ> static void hex_row()
@@ -202,12 +207,13 @@ template <int NQ> static void hex_row()
     fill_basis(g_b, NQ - 1, NQ, 0);
     CK(hipDeviceSynchronize());
     constexpr int M = HexCfg<NQ>::MF;
-    hex_one<NQ, M>();
-    hex_one<NQ, M ^ 8>();
-    hex_one<NQ, M ^ 12>();
-    hex_one<NQ, M>();
-    hex_one<NQ, M ^ 8>();
-    hex_one<NQ, M ^ 12>();
+    constexpr int B = M & 15; // alignment bits of the row; XG (bits 4+) swept below
+    hex_one<NQ, B>();
+    hex_one<NQ, B | (16 << 4)>();
+    hex_one<NQ, B | (64 << 4)>();
+    hex_one<NQ, B>();
+    hex_one<NQ, B | (16 << 4)>();
+    hex_one<NQ, B | (64 << 4)>();
 }
 
 template <int NQ> static void quad_row()
@@ -215,12 +221,13 @@ template <int NQ> static void quad_row()
     fill_basis(g_b, NQ - 1, NQ, 0);
     CK(hipDeviceSynchronize());
     constexpr int M = QuadCfg<NQ>::MF;
-    quad_one<NQ, M>();
-    quad_one<NQ, M ^ 8>();
-    quad_one<NQ, M ^ 12>();
-    quad_one<NQ, M>();
-    quad_one<NQ, M ^ 8>();
-    quad_one<NQ, M ^ 12>();
+    constexpr int B = M & 15; // alignment bits of the row; XG (bits 4+) swept below
+    quad_one<NQ, B>();
+    quad_one<NQ, B | (16 << 4)>();
+    quad_one<NQ, B | (64 << 4)>();
+    quad_one<NQ, B>();
+    quad_one<NQ, B | (16 << 4)>();
+    quad_one<NQ, B | (64 << 4)>();
     if constexpr (NQ >= 11)
     {
         quad_mfma_one<NQ, false>();
