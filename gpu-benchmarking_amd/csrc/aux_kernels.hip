@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2_t *
 __global__ __launch_bounds__(256) void vector_add_kernel(double *__restrict__ x,
                                                          const double *__restrict__ y, uint64_t n)
 {
-    const uint64_t v  = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // runs of 256 neighbouring workgroups (1 MiB of each stream) per XCD: 6.45 -> 6.65 TB/s
+    // (tools/sf_membench7, profiles/r01/membench7_xcd_runs_on_streams.log)
+    const uint64_t v  = logical_block<256>() * 256 + threadIdx.x;
     const uint64_t nv = n / 2;
     if (v < nv)
     {

@@ -152,25 +152,6 @@ struct ChunkIter
     uint64_t first, step, count;
 };
 
-// Workgroups are dealt round-robin to the 8 XCDs (one L2 each).  XG > 0 renumbers them so that runs of XG
-// consecutive LOGICAL workgroups -- neighbours in memory -- execute on the same XCD, inside a window of 8*XG
-// workgroups that keeps the DRAM access front as compact as before (the grid must be a multiple of 8*XG or the
-// tail window falls back to the identity).
-template <int XG> __device__ __forceinline__ uint64_t logical_block()
-{
-    const uint64_t b = blockIdx.x;
-    if constexpr (XG <= 0)
-        return b;
-    else
-    {
-        constexpr uint64_t W = 8ull * XG;
-        const uint64_t win = b / W, r = b - win * W;
-        if ((win + 1) * W > gridDim.x)
-            return b; // partial tail window
-        return win * W + (r & 7) * XG + (r >> 3);
-    }
-}
-
 template <int KMAP, int WPB, int XG = 0>
 __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
 {
