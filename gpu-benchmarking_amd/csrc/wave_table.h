@@ -26,11 +26,11 @@ template <int NQ> struct HexCfg;
 SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16, 0); //  73 /  70
 SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
 SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 227 / 223
-SF_HEX_CFG(5,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG16 | 8);  // 247 / 243
-SF_HEX_CFG(6,  2,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 278 / 272
-SF_HEX_CFG(7,  1,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 285 / 283 (one element per wave; output via the word-grid store)
+SF_HEX_CFG(5,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 8);  // 267 (profiles/r01/tune_hex5_xcd_runs.log)
+SF_HEX_CFG(6,  2,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 284
+SF_HEX_CFG(7,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 305 (one element per wave; output via the word-grid store)
 SF_HEX_CFG(8,  1,   8, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 322 / 316-320 (without XCD runs, 4 waves/block: 312; four-element chunks: 285-303)
-SF_HEX_CFG(9,  1,   2, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 305 / 303
+SF_HEX_CFG(9,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 317
 SF_HEX_CFG(10, 1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 313 / 309 (two-element chunks: 305 / 300)
 SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
