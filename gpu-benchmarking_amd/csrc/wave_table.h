@@ -77,11 +77,11 @@ SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue
 // The memory flags are tuned separately (tools/sf_tune_table hexf32 / quadf32).
 constexpr int hex_f32_mf(int nq)
 {
-    return ((nq % 2 && nq >= 3) ? 8 : 0) | (nq >= 4 ? XG64 : 0); // odd orders: line-aligned output; XCD runs
+    return ((nq % 2 && nq >= 3) ? 8 : 0) | (nq >= 7 ? XG64 : 0); // odd orders: line-aligned output; XCD runs from nq = 7 (+3-6 %)
 }
 constexpr int quad_f32_mf(int nq)
 {
-    return (nq == 15 ? 12 : ((nq == 7 || nq == 9 || nq == 11) ? 8 : 0)) | (nq >= 8 ? XG64 : 0);
+    return (nq == 15 ? 12 : ((nq == 7 || nq == 9 || nq == 11) ? 8 : 0)) | (nq >= 12 ? XG64 : 0);
 }
 template <int NQ> struct HexCfgF32
 {
