@@ -25,7 +25,7 @@ template <int NQ> struct HexCfg;
 //          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
 SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16, 0); //  73 /  70
 SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
-SF_HEX_CFG(4,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 227 / 223
+SF_HEX_CFG(4,  4,   8, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 237 (EC 8, 4 waves/block: 229)
 SF_HEX_CFG(5,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 8);  // 267 (profiles/r01/tune_hex5_xcd_runs.log)
 SF_HEX_CFG(6,  2,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 284
 SF_HEX_CFG(7,  1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 305 (one element per wave; output via the word-grid store)
