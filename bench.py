@@ -275,7 +275,7 @@ def extras(sf, torch, dev, nelmt=1 << 20, reps=10):
         out["hex_sweep"][str(nq)] = {"gdof_s": round(nelmt * nm ** 3 / ms * 1e-6, 2),
                                      "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         del x, o
-    for nq in (8, 16, 32):
+    for nq in (8, 16, 20, 24, 32):  # 20 / 24: vector-ALU kernel past the crossover; 16 / 32: matrix cores
         nm = nq - 1
         b = sf.fill_basis(nm, nq, dev)
         x = sf.fill_random(nelmt * nm ** 2, 1, 0, dev)
