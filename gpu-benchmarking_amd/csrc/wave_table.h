@@ -90,6 +90,10 @@ template <int NQ> struct HexCfgF32
 };
 // nq = 7, 9: the fp64 rows moved to one element per chunk (their odd nq^3 output then leaves through the 8-byte
 // word-grid store, which is fp64-only); fp32 keeps the two-element-based rule (566 / 585 GDOF/s against 492 / 520)
+template <> struct HexCfgF32<6>
+{
+    static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = 0; // 552 (8 waves/block: 527)
+};
 template <> struct HexCfgF32<7>
 {
     static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = XG64 | 8;
