@@ -54,7 +54,7 @@ template <int NQ, int EC, int WPB> constexpr size_t mfma_lds_bytes()
 
 // staging registers -> LDS, element e row q at e*ESTRIDE + q*S
 template <class G>
-__device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double *slab, int lane)
+__device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double *slab, int lane, int sh)
 {
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k)
@@ -71,12 +71,18 @@ __device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double
                 slab[e1 * G::ESTRIDE + (r1 - e1 * G::NM) * G::S + (f1 - r1 * G::NM)] = st[k].y;
             }
         }
-        else
+        else if (k < word_grid_regs<G::IN_DBL, double>())
         {
-            if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
+            // word-grid registers (chunk_load_any): word v holds doubles 2v - sh + {0, 1}
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
             {
-                const int r0 = v / G::NM, e0 = r0 / G::NM;
-                slab[e0 * G::ESTRIDE + (r0 - e0 * G::NM) * G::S + (v - r0 * G::NM)] = st[k].x;
+                const int f = 2 * v - sh + h;
+                if (f >= 0 && f < G::IN_DBL)
+                {
+                    const int r0 = f / G::NM, e0 = r0 / G::NM;
+                    slab[e0 * G::ESTRIDE + (r0 - e0 * G::NM) * G::S + (f - r0 * G::NM)] = st[k][h];
+                }
             }
         }
     }
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        mfma_stage<G>(st, slab, lane);
+        mfma_stage<G>(st, slab, lane, G::VEC2 ? 0 : line_offset<double>(in + c * G::IN_DBL));
         wave_lds_fence();
         if (n + 1 < it.count)
             chunk_fetch<GW, EC>(st, in, c + it.step, nelmt, lane);
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                     }
                 }
             }
-            else if (k < cdiv(G::IN_DBL + 15, 2 * kWave))
+            else if (k < word_grid_regs<G::IN_DBL, double>())
             {
                 const int a0 = line_offset_f64(in + c * G::IN_DBL);
 #pragma unroll

@@ -184,37 +184,60 @@ __device__ __forceinline__ ChunkIter chunk_iter(uint64_t nchunk, int wib)
     return it;
 }
 
-// Chunk load for a source that is only 8-byte aligned (odd scalars per chunk): the mirror image of
-// flush_any_f64 below.  Lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk
-// starts in; st[k] = {src[d0], src[d0 + 1]}, d0 = 2*(k*64 + l) - a, zero outside [0, nvalid).  Every load is a
-// whole aligned 16-B word; the at most two half words at the ends are 8-byte loads.
+// Word-grid accesses for a chunk whose base is only scalar-aligned (a number of scalars per chunk that is not a
+// multiple of the 16-byte lane: one element of an even order in fp64, most single elements in fp32).  Lane
+// k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the chunk starts in: word w holds the
+// scalars VW*w - a + {0 .. VW-1}, a = scalars between the line start and the chunk base.  Interior words are whole
+// aligned 16-byte accesses and every wave-wide instruction covers whole lines; the words that straddle the two
+// ends are completed with scalar accesses.
+template <typename T> __device__ __forceinline__ int line_offset(const void *p)
+{
+    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p / sizeof(T)) & (128 / sizeof(T) - 1)));
+}
 __device__ __forceinline__ int line_offset_f64(const void *p)
 {
-    return __builtin_amdgcn_readfirstlane((int)(((uintptr_t)p >> 3) & 15)); // doubles into the 128-B line
+    return line_offset<double>(p);
+}
+
+template <int NMAX, typename T> constexpr int word_grid_regs()
+{
+    return cdiv(NMAX + (int)(128 / sizeof(T)) - 1, (int)(16 / sizeof(T)) * kWave);
+}
+
+template <int NMAX, int NREG, typename T>
+__device__ __forceinline__ void chunk_load_any(typename VecOf<T>::type (&st)[NREG], const T *__restrict__ src,
+                                               int lane, int nvalid)
+{
+    using V          = typename VecOf<T>::type;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int NLDA = word_grid_regs<NMAX, T>();
+    static_assert(NLDA <= NREG, "staging registers");
+    const int a   = line_offset<T>(src);
+    const V *grid = reinterpret_cast<const V *>(src - a);
+#pragma unroll
+    for (int k = 0; k < NLDA; ++k)
+    {
+        const int gv = k * kWave + lane;
+        const int d0 = VW * gv - a;
+        V x          = {};
+        if (d0 >= 0 && d0 + VW - 1 < nvalid)
+            x = __builtin_nontemporal_load(grid + gv);
+        else
+        {
+#pragma unroll
+            for (int h = 0; h < VW; ++h)
+                if (d0 + h >= 0 && d0 + h < nvalid)
+                    x[h] = src[d0 + h];
+        }
+        st[k] = x;
+    }
 }
 
 template <int NMAX, int NREG>
 __device__ __forceinline__ void chunk_load_any_f64(double2_t (&st)[NREG], const double *__restrict__ src,
                                                    int lane, int nvalid)
 {
-    constexpr int NLDA = cdiv(NMAX + 15, 2 * kWave);
-    static_assert(NLDA <= NREG, "staging registers");
-    const int a           = line_offset_f64(src);
-    const double2_t *grid = reinterpret_cast<const double2_t *>(src - a);
-#pragma unroll
-    for (int k = 0; k < NLDA; ++k)
-    {
-        const int gv = k * kWave + lane;
-        const int d0 = 2 * gv - a, d1 = d0 + 1;
-        double2_t x  = {0.0, 0.0};
-        if (d0 >= 0 && d1 < nvalid)
-            x = __builtin_nontemporal_load(grid + gv);
-        else if (d1 >= 0 && d1 < nvalid)
-            x.y = src[d1];
-        else if (d0 >= 0 && d0 < nvalid)
-            x.x = src[d0];
-        st[k] = x;
-    }
+    chunk_load_any<NMAX, NREG, double>(st, src, lane, nvalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,22 +283,10 @@ __device__ __forceinline__ void chunk_load(typename G::Vec (&st)[G::NLD],
             }
         }
     }
-    else if constexpr (sizeof(T) == 8)
-    {
-        // odd number of doubles per chunk (every other chunk only 8-byte aligned): 16-byte word-grid load
-        chunk_load_any_f64<G::IN_DBL>(st, src, lane, FULL ? G::IN_DBL : nvalid);
-    }
     else
     {
-#pragma unroll
-        for (int k = 0; k < G::NLD; ++k)
-        {
-            const int v = k * kWave + lane;
-            T x         = 0;
-            if (v < (FULL ? G::IN_DBL : nvalid))
-                x = NTL ? __builtin_nontemporal_load(src + v) : src[v];
-            st[k][0] = x;
-        }
+        // scalars per chunk not a multiple of the 16-byte lane (chunk bases only scalar-aligned): word-grid load
+        chunk_load_any<G::IN_DBL, G::NLD, T>(st, src, lane, FULL ? G::IN_DBL : nvalid);
     }
 }
 
@@ -311,16 +322,16 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
             }
         }
     }
-    else if constexpr (sizeof(typename G::Scalar) == 8)
+    else
     {
-        // word-grid registers (chunk_load_any_f64): word k*64 + lane holds scalars 2*(k*64 + lane) - sh + {0, 1},
-        // sh = line_offset_f64(chunk base)
+        // word-grid registers (chunk_load_any): word k*64 + lane holds scalars VW*(k*64 + lane) - sh + {0..VW-1},
+        // sh = line_offset(chunk base)
 #pragma unroll
-        for (int k = 0; k < cdiv(G::IN_DBL + 15, 2 * kWave); ++k)
+        for (int k = 0; k < word_grid_regs<G::IN_DBL, typename G::Scalar>(); ++k)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < VW; ++h)
             {
-                const int f = 2 * (k * kWave + lane) - sh + h;
+                const int f = VW * (k * kWave + lane) - sh + h;
                 if (f >= 0 && f < G::IN_DBL)
                 {
                     if constexpr (G::IN_STRIDE == G::NM)
@@ -329,21 +340,6 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
                         slab[f + f / G::NM] = st[k][h];
                 }
             }
-    }
-    else
-    {
-#pragma unroll
-        for (int k = 0; k < G::NLD; ++k)
-        {
-            const int v = k * kWave + lane;
-            if ((k + 1) * kWave <= G::IN_DBL || v < G::IN_DBL)
-            {
-                if constexpr (G::IN_STRIDE == G::NM)
-                    slab[v] = st[k][0];
-                else
-                    slab[v + v / G::NM] = st[k][0];
-            }
-        }
     }
 }
 
@@ -548,31 +544,44 @@ __device__ __forceinline__ void store_column(const T (&acc)[NOUT], T *dst, int l
     }
 }
 
-// Flat fp64 stream LDS -> HBM for a destination that is only 8-byte aligned (odd nq^d, odd element index):
-// lane k*64 + l owns the 16-byte word number k*64 + l of the 128-byte-line grid the destination starts in, so
-// every store is a whole aligned 16-B word and every wave-wide instruction covers whole lines; the at most
-// two half words at the ends are scalar stores.  LDS side: two 8-byte reads per lane (any 8-B alignment).
-template <int NMAX>
-__device__ __forceinline__ void flush_any_f64(const double *img, double *__restrict__ dst, int nout, int lane)
+// Flat stream LDS -> HBM for a destination that is only scalar-aligned (see the word-grid note above):
+// whole aligned 16-byte stores on the 128-byte-line grid, scalar stores for the words straddling the two ends.
+// LDS side: VW scalar reads per lane (any scalar alignment).
+template <int NMAX, typename T>
+__device__ __forceinline__ void flush_any(const T *img, T *__restrict__ dst, int nout, int lane)
 {
-    const int a     = line_offset_f64(dst);
-    double2_t *grid = reinterpret_cast<double2_t *>(dst - a);
-    constexpr int NST = cdiv(NMAX + 15, 2 * kWave);
+    using V          = typename VecOf<T>::type;
+    constexpr int VW = VecOf<T>::W;
+    const int a      = line_offset<T>(dst);
+    V *grid          = reinterpret_cast<V *>(dst - a);
+    constexpr int NST = word_grid_regs<NMAX, T>();
 #pragma unroll
     for (int k = 0; k < NST; ++k)
     {
         const int gv = k * kWave + lane;
-        const int d0 = 2 * gv - a, d1 = d0 + 1;
-        if (d0 >= 0 && d1 < nout)
+        const int d0 = VW * gv - a;
+        if (d0 >= 0 && d0 + VW - 1 < nout)
         {
-            const double2_t x = {img[d0], img[d1]};
+            V x;
+#pragma unroll
+            for (int h = 0; h < VW; ++h)
+                x[h] = img[d0 + h];
             __builtin_nontemporal_store(x, grid + gv);
         }
-        else if (d1 >= 0 && d1 < nout) // d0 == -1: the word straddles the start
-            dst[d1] = img[d1];
-        else if (d0 >= 0 && d0 < nout) // d1 == nout: the word straddles the end
-            dst[d0] = img[d0];
+        else
+        {
+#pragma unroll
+            for (int h = 0; h < VW; ++h)
+                if (d0 + h >= 0 && d0 + h < nout)
+                    dst[d0 + h] = img[d0 + h];
+        }
     }
+}
+
+template <int NMAX>
+__device__ __forceinline__ void flush_any_f64(const double *img, double *__restrict__ dst, int nout, int lane)
+{
+    flush_any<NMAX, double>(img, dst, nout, lane);
 }
 
 // OUT_LDS epilogue: the slab holds the chunk's output in final layout; stream `nout` scalars to HBM
@@ -613,26 +622,10 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
             }
         }
     }
-    else if constexpr (sizeof(typename G::Scalar) == 8)
-    {
-        // odd number of doubles per chunk: every other chunk is only 8-byte aligned
-        flush_any_f64<G::OUT_DBL>(slab, dst, nout, lane);
-    }
     else
     {
-        constexpr int NST = cdiv(G::OUT_DBL, kWave);
-#pragma unroll
-        for (int k = 0; k < NST; ++k)
-        {
-            const int v = k * kWave + lane;
-            if (v < nout)
-            {
-                if (NTS)
-                    __builtin_nontemporal_store(slab[v], dst + v);
-                else
-                    dst[v] = slab[v];
-            }
-        }
+        // scalars per chunk not a multiple of the 16-byte lane: chunk bases are only scalar-aligned
+        flush_any<G::OUT_DBL, typename G::Scalar>(slab, dst, nout, lane);
     }
 }
 
@@ -676,7 +669,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
 
         chunk_stage<G, AL>(st, slab, lane,
                            G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
-                                   : (sizeof(T) == 8 ? line_offset_f64(in + c * G::IN_DBL) : 0));
+                                   : line_offset<T>(in + c * G::IN_DBL));
         wave_lds_fence();
 
         // request the next chunk of this wave now; it lands in the staging registers while this
@@ -809,7 +802,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
 
         chunk_stage<G, AL>(st, slab, lane,
                            G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
-                                   : (sizeof(T) == 8 ? line_offset_f64(in + c * G::IN_DBL) : 0));
+                                   : line_offset<T>(in + c * G::IN_DBL));
         wave_lds_fence();
         if (n + 1 < it.count)
             chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);

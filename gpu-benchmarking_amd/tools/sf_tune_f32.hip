@@ -58,16 +58,16 @@ static void run(const char *label, double dof, double bytes, float *out, size_t 
     std::fflush(stdout);
 }
 
-template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS, int MEMF = 0>
 void hex_case(const HexArgsT<float> &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex f32 nq%d EC%d WPB%d %s MW%d K%d o%d", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT);
+    std::snprintf(label, sizeof label, "hex f32 nq%d EC%d WPB%d %s MW%d K%d o%d mf%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT, MEMF);
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 4.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
-        [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, 0, float>(a, 0); });
+        [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF, float>(a, 0); });
 }
 
 template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS>
@@ -97,18 +97,18 @@ int main(int argc, char **argv)
     fill_random_f32(in, nelmt * NM * NM * NM, 0x5F3759DF, 0, 0);
     CK(hipDeviceSynchronize());
     HexArgsT<float> h{b, b, b, in, nullptr, out, nelmt};
-    hex_case<8, 8, 4, BASIS_SMEM, 2, 2>(h);
-    hex_case<8, 4, 4, BASIS_SMEM, 2, 2>(h);
-    hex_case<8, 4, 4, BASIS_SMEM, 4, 2>(h);
-    hex_case<8, 4, 4, BASIS_SMEM, 4, 1>(h);
-    hex_case<8, 4, 4, BASIS_SMEM, 4, 4>(h);
-    hex_case<8, 8, 4, BASIS_SMEM, 4, 1>(h);
-    hex_case<8, 8, 4, BASIS_SMEM, 4, 2>(h);
-    hex_case<8, 8, 4, BASIS_LDS, 4, 2>(h);
-    hex_case<8, 16, 4, BASIS_SMEM, 2, 1>(h);
-    hex_case<8, 8, 8, BASIS_SMEM, 4, 2>(h);
-    hex_case<8, 4, 8, BASIS_SMEM, 4, 2>(h);
-    hex_case<8, 8, 4, BASIS_SMEM, 4, 2, OUT_ST8>(h);
+    for (int rep = 0; rep < 2; ++rep)
+    {
+        hex_case<8, 2, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h); // table row (fp64 row x 2 elements), XCD runs of 64
+        hex_case<8, 1, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h); // one element per wave: 1372-byte inputs, word grid
+        hex_case<8, 1, 8, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 1, 8, BASIS_SMEM, 8, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 2, 8, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 3, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 3, 8, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 4, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+        hex_case<8, 8, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
+    }
     QuadArgsT<float> q{b, b, in, nullptr, out, nelmt};
     quad_case<8, 16, 4, BASIS_SMEM, 2, 1>(q);
     quad_case<8, 16, 4, BASIS_SMEM, 4, 1>(q);
