@@ -629,6 +629,58 @@ __device__ __forceinline__ void chunk_flush(const typename G::Scalar *slab,
     }
 }
 
+// Workgroup-cooperative input (MEMF bit 16, K = 1 mappings): the WPB chunks of a workgroup are contiguous, so all
+// its lanes load them as ONE flat word-grid stream -- every 128-byte line of the workgroup's input is fetched once,
+// the words straddling two elements included -- and scatter the words into the owners' slabs; one workgroup
+// barrier, then every wave computes its own chunk as usual.
+template <class G, int WPB, int SLAB>
+__device__ __forceinline__ void block_load_stage(typename G::Scalar *slab0, const typename G::Scalar *__restrict__ src,
+                                                 int nvalid)
+{
+    using T          = typename G::Scalar;
+    using V          = typename G::Vec;
+    constexpr int VW = G::VW;
+    constexpr int NB = WPB * G::IN_DBL;
+    constexpr int NT = WPB * kWave;
+    constexpr int NW = cdiv(cdiv(NB + (int)(128 / sizeof(T)) - 1, VW), NT);
+    const int a      = line_offset<T>(src);
+    const V *grid    = reinterpret_cast<const V *>(src - a);
+    V x[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+    {
+        const int gv = k * NT + (int)threadIdx.x;
+        const int d0 = VW * gv - a;
+        V v          = {};
+        if (d0 >= 0 && d0 + VW - 1 < nvalid)
+            v = __builtin_nontemporal_load(grid + gv);
+        else
+        {
+#pragma unroll
+            for (int h = 0; h < VW; ++h)
+                if (d0 + h >= 0 && d0 + h < nvalid)
+                    v[h] = src[d0 + h];
+        }
+        x[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int h = 0; h < VW; ++h)
+        {
+            const int f = VW * (k * NT + (int)threadIdx.x) - a + h;
+            if (f >= 0 && f < NB)
+            {
+                const int w = f / G::IN_DBL, r = f - w * G::IN_DBL;
+                T *dst      = slab0 + w * SLAB;
+                if constexpr (G::IN_STRIDE == G::NM)
+                    dst[r] = x[k][h];
+                else
+                    dst[r + r / G::NM] = x[k][h];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3D hex
 // ------------------------------------------------------------------------------------------------
@@ -652,14 +704,29 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
     const T *bs[3];
     T *slab = wave_setup<G, 3, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
+    constexpr int XG  = (MEMF >> 4) & 0xfff;
+    constexpr bool BL = ((MEMF >> 16) & 1) != 0; // workgroup-cooperative input
+    static_assert(!BL || (KMAP == 1 && BMODE != BASIS_LDS), "cooperative input: one chunk per wave, basis in SGPRs");
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB, (MEMF >> 4)>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
+    if constexpr (BL)
+    {
+        const uint64_t first = logical_block<XG>() * (uint64_t)(WPB * EC); // first element of the workgroup
+        if (first < nelmt)
+        {
+            const uint64_t left = nelmt - first;
+            block_load_stage<G, WPB, SLAB>(lds, in + first * G::NMT,
+                                           left >= (uint64_t)(WPB * EC) ? WPB * G::IN_DBL : (int)left * G::NMT);
+        }
+        __syncthreads();
+    }
     if (it.count == 0)
         return;
 
     constexpr bool AL = (MEMF & 4) && G::ALIGN_OK;
-    typename G::Vec st[G::NLD];
-    chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, it.first, nelmt, lane);
+    typename G::Vec st[BL ? 1 : G::NLD];
+    if constexpr (!BL)
+        chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -667,15 +734,18 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_wave_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        chunk_stage<G, AL>(st, slab, lane,
-                           G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
-                                   : line_offset<T>(in + c * G::IN_DBL));
-        wave_lds_fence();
+        if constexpr (!BL)
+        {
+            chunk_stage<G, AL>(st, slab, lane,
+                               G::VEC2 ? (AL ? align_shift(in + c * G::IN_DBL) : 0)
+                                       : line_offset<T>(in + c * G::IN_DBL));
+            wave_lds_fence();
 
-        // request the next chunk of this wave now; it lands in the staging registers while this
-        // chunk is being computed
-        if (n + 1 < it.count)
-            chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);
+            // request the next chunk of this wave now; it lands in the staging registers while this
+            // chunk is being computed
+            if (n + 1 < it.count)
+                chunk_fetch<G, EC, !(MEMF & 1), AL>(st, in, c + it.step, nelmt, lane);
+        }
 
         // ---- direction 0: w1[(e,i,r)][q] = sum_p in[(e,r,q)][p] * B0[p][i] ----------------------
         {
@@ -786,7 +856,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_wave_kernel(
     T *slab = wave_setup<G, 2, WPB, BMODE, SLAB>(lds, gb, bs, wib);
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
-    const ChunkIter it    = chunk_iter<KMAP, WPB, (MEMF >> 4)>(nchunk, wib);
+    const ChunkIter it    = chunk_iter<KMAP, WPB, ((MEMF >> 4) & 0xfff)>(nchunk, wib);
     if (it.count == 0)
         return;
 

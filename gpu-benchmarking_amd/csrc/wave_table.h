@@ -9,7 +9,7 @@ namespace sf
 
 // MF: memory flags of the kernel (bit 0: plain instead of non-temporal loads, bit 1: plain stores,
 // bit 2: shift the chunk's 16-byte lanes so every wave-wide load covers whole 128-byte lines,
-// bit 3: the same for the OUT_LDS output stream, bits 4+: XG = MF >> 4, runs of XG neighbouring workgroups per XCD)
+// bit 3: the same for the OUT_LDS output stream, bits 4-15: XG, runs of XG neighbouring workgroups per XCD, bit 16: workgroup-cooperative input -- measured, not used)
 // NQ -> elements per chunk, waves per block, basis delivery, min waves/SIMD, chunk mapping
 // (0 = persistent), 16-byte stores
 // XCD grouping (bwdtrans_wave.h, logical_block()): runs of XG neighbouring workgroups execute on the same XCD

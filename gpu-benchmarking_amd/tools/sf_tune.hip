@@ -82,7 +82,7 @@ void hex_case(const HexArgs &a)
     char label[96];
     char xg[16] = "";
     if (MEMF >= 16)
-        std::snprintf(xg, sizeof xg, " xg%d", MEMF >> 4);
+        std::snprintf(xg, sizeof xg, " xg%d%s", (MEMF >> 4) & 0xfff, (MEMF >> 16) & 1 ? " coop" : "");
     std::snprintf(label, sizeof label, "hex nq%d EC%d WPB%d %s MW%d K%d %s%s%s", NQ, EC, WPB,
                   BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")),
                   MW, KM, out_name(OUT),
