@@ -40,11 +40,13 @@ enum
     SF_ENOMEM    = -4  /* internal workspace allocation failed */
 };
 
-/* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest known. */
+/* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest known: 3D isotropic nq 2..11
+ * WAVE, 12..16 MFMA; 2D isotropic nq 2..11 and 17..24 WAVE, 12..16 and 25..32 MFMA; anything else (anisotropic,
+ * buffers not 16-byte aligned, higher orders) GENERIC. */
 enum
 {
     SF_VARIANT_AUTO       = 0,
-    SF_VARIANT_WAVE       = 1, /* flagship: one wavefront streams chunks of elements, LDS-staged */
+    SF_VARIANT_WAVE       = 1, /* flagship: one wavefront per chunk of elements (3D nq 2..11, 2D nq 2..24, 32) */
     SF_VARIANT_THREAD     = 2, /* one thread per element, fused nest  (cf. benchmark05.cc:15-102)  */
     SF_VARIANT_BLOCK_LDS  = 3, /* one workgroup per element, 3 sweeps in LDS (cf. :291-429)       */
     SF_VARIANT_BLOCK_GLB  = 4, /* one workgroup per element, global workspace (cf. :203-289)       */
