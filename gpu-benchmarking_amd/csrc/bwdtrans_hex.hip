@@ -18,8 +18,51 @@ template <int NQ> struct HexSmall
     static constexpr int OUT = HexCfg<NQ>::OUT;
 };
 
+// nq = 2 (one mode per element): out[e][k][j][i] = ((in[e] * B0[i]) * B1[j]) * B2[k] -- no sweep has anything to
+// sum, so the element is a pure stream: one 16-byte output pair (i = 0, 1) per lane, four lanes per element, the
+// input value re-read through the cache.  Same multiplication order as the sweeps, hence bit-identical results.
+__global__ __launch_bounds__(256) void hex_nq2_stream_kernel(const double *__restrict__ b0,
+                                                             const double *__restrict__ b1,
+                                                             const double *__restrict__ b2,
+                                                             const double *__restrict__ in,
+                                                             double *__restrict__ out, uint64_t nelmt)
+{
+    constexpr int U   = 4; // output pairs per thread
+    const uint64_t nv = nelmt * 4;
+    const double c0 = b0[0], c1 = b0[1];
+    double2_t *out2 = reinterpret_cast<double2_t *>(out);
+    const uint64_t base = logical_block<64>() * (256ull * U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+        const uint64_t v = base + (uint64_t)u * 256;
+        if (v < nv)
+        {
+            const int p    = (int)(v & 3); // pair index inside the element: j = p & 1, k = p >> 1
+            const double x = in[v >> 2];
+            const double bj = b1[p & 1], bk = b2[p >> 1];
+            const double2_t r = {((x * c0) * bj) * bk, ((x * c1) * bj) * bk};
+            __builtin_nontemporal_store(r, out2 + v);
+        }
+    }
+}
+
+static int launch_hex_nq2(const HexArgs &a, hipStream_t s)
+{
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t blocks = (a.nelmt * 4 + 1023) / 1024;
+    if (blocks > 0x7fffffffull)
+        return SF_EINVAL;
+    hex_nq2_stream_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
 template <int NQ> static int go(const HexArgs &a, hipStream_t s)
 {
+    if constexpr (NQ == 2)
+        return launch_hex_nq2(a, s);
     using C = HexCfg<NQ>;
     constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
     if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)

@@ -13,8 +13,48 @@ template <int NQ> struct QuadSmall
     static constexpr int EC = (QuadCfg<NQ>::EC / 4 + 1) / 2 * 2 < 2 ? 2 : (QuadCfg<NQ>::EC / 4 + 1) / 2 * 2;
 };
 
+// nq = 2 (one mode per element): out[e][j][i] = (in[e] * B0[i]) * B1[j]: a pure stream, two lanes per element
+// (see hex_nq2_stream_kernel in bwdtrans_hex.hip)
+__global__ __launch_bounds__(256) void quad_nq2_stream_kernel(const double *__restrict__ b0,
+                                                              const double *__restrict__ b1,
+                                                              const double *__restrict__ in,
+                                                              double *__restrict__ out, uint64_t nelmt)
+{
+    constexpr int U   = 4;
+    const uint64_t nv = nelmt * 2;
+    const double c0 = b0[0], c1 = b0[1];
+    double2_t *out2 = reinterpret_cast<double2_t *>(out);
+    const uint64_t base = (uint64_t)blockIdx.x * (256ull * U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+        const uint64_t v = base + (uint64_t)u * 256;
+        if (v < nv)
+        {
+            const double x  = in[v >> 1];
+            const double bj = b1[v & 1];
+            const double2_t r = {(x * c0) * bj, (x * c1) * bj};
+            __builtin_nontemporal_store(r, out2 + v);
+        }
+    }
+}
+
+static int launch_quad_nq2(const QuadArgs &a, hipStream_t s)
+{
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t blocks = (a.nelmt * 2 + 1023) / 1024;
+    if (blocks > 0x7fffffffull)
+        return SF_EINVAL;
+    quad_nq2_stream_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
 template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
 {
+    if constexpr (NQ == 2)
+        return launch_quad_nq2(a, s);
     using C = QuadCfg<NQ>;
     constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
     if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
