@@ -69,7 +69,7 @@ SF_QUAD_CFG(21, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  XG64); // 329 (257)
 SF_QUAD_CFG(22, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 308 (247)
 SF_QUAD_CFG(23, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST8,  XG64); // 306 (260)
 SF_QUAD_CFG(24, 2,   4, BASIS_SMEM_COLS16, 2, 1, OUT_ST16, XG64); // 282 (270)
-SF_QUAD_CFG(32, 2,   4, BASIS_LDS,  1, 4, OUT_ST16, 0); // 118 / 117: VALU-issue-bound (MFMA path: next)
+SF_QUAD_CFG(32, 2,   4, BASIS_SMEM_COLS16, 1, 2, OUT_ST16, 0); // 135 (LDS copy of the basis: 118): VALU-issue-bound; AUTO uses the matrix cores (340)
 #undef SF_QUAD_CFG
 
 // fp32 rows follow from the fp64 ones: twice the elements per chunk (the same bytes), twice the waves per
