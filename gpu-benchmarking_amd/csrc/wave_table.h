@@ -108,4 +108,16 @@ template <int NQ> struct QuadCfgF32
     static constexpr int MW = QuadCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = quad_f32_mf(NQ);
 };
 
+// fp32, 2D nq = 12, 15, 16: the doubled chunks (16-20 elements) leave 8 waves per CU; four-element chunks measure
+// 726 / 705 / 723 GDOF/s against 670 / 528 / 640 (profiles/r01/tune_f32_chunk_size_2d.log)
+#define SF_QUAD_F32(NQ_, MF_)                                                                      \
+    template <> struct QuadCfgF32<NQ_>                                                             \
+    {                                                                                              \
+        static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM_COLS16, MW = 4, KM = 1, OUT = OUT_LDS, MF = MF_; \
+    }
+SF_QUAD_F32(12, XG64);
+SF_QUAD_F32(15, XG64 | 12);
+SF_QUAD_F32(16, XG64);
+#undef SF_QUAD_F32
+
 } // namespace sf

@@ -70,16 +70,16 @@ void hex_case(const HexArgsT<float> &a)
         [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF, float>(a, 0); });
 }
 
-template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT = OUT_LDS, int MEMF = 0>
 void quad_case(const QuadArgsT<float> &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad f32 nq%d EC%d WPB%d %s MW%d K%d o%d", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT);
+    std::snprintf(label, sizeof label, "quad f32 nq%d EC%d WPB%d bm%d MW%d K%d o%d mf%d", NQ, EC, WPB, BM, MW, KM, OUT,
+                  MEMF);
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm, a.nelmt * 4.0 * (nm * nm + (double)NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ,
-        [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, 0, float>(a, 0); });
+        [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF, float>(a, 0); });
 }
 
 int main(int argc, char **argv)
@@ -110,11 +110,24 @@ int main(int argc, char **argv)
         hex_case<8, 8, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(h);
     }
     QuadArgsT<float> q{b, b, in, nullptr, out, nelmt};
-    quad_case<8, 16, 4, BASIS_SMEM, 2, 1>(q);
     quad_case<8, 16, 4, BASIS_SMEM, 4, 1>(q);
-    quad_case<8, 32, 4, BASIS_SMEM, 2, 1>(q);
-    quad_case<8, 32, 4, BASIS_SMEM, 4, 1>(q);
-    quad_case<8, 32, 4, BASIS_SMEM, 4, 2>(q);
-    quad_case<8, 64, 4, BASIS_SMEM, 2, 1>(q);
+    // nq 15 / 16: the derived rows (16 elements per chunk) leave 8 waves per CU; smaller chunks
+    float *b2;
+    CK(hipMalloc((void **)&b2, sizeof(float) * 16 * 16));
+    for (int rep = 0; rep < 2; ++rep)
+    {
+#define ROW(NQ, MF)                                                                                \
+    {                                                                                              \
+        fill_basis_f32(b2, NQ - 1, NQ, 0);                                                         \
+        QuadArgsT<float> qq{b2, b2, in, nullptr, out, nelmt};                                      \
+        quad_case<NQ, 16, 4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, MF>(qq);                            \
+        quad_case<NQ, 8, 4, BASIS_SMEM_COLS16, 4, 1, OUT_LDS, MF>(qq);                             \
+        quad_case<NQ, 4, 4, BASIS_SMEM_COLS16, 4, 1, OUT_LDS, MF>(qq);                             \
+        quad_case<NQ, 4, 8, BASIS_SMEM_COLS16, 4, 1, OUT_LDS, MF>(qq);                             \
+        quad_case<NQ, 2, 8, BASIS_SMEM_COLS16, 4, 1, OUT_LDS, MF>(qq);                             \
+    }
+        ROW(12, 1024) ROW(13, 1036) ROW(14, 1024) ROW(15, 1036) ROW(16, 1024) ROW(20, 1024) ROW(24, 1024)
+#undef ROW
+    }
     return 0;
 }
