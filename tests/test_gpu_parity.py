@@ -300,6 +300,16 @@ def test_line_alignment_offsets(sf, oracle, torch_mod, dim):
             assert bool((head == -7.0).all()) and bool((tail == -7.0).all()), (dim, nq, nelmt)
 
 
+@pytest.mark.parametrize("dim,nq", [(3, 8), (3, 10), (3, 5), (3, 13), (2, 16), (2, 20), (2, 28), (2, 9)])
+def test_xcd_window_tails(sf, oracle, dim, nq):
+    """Workgroups are renumbered in windows of 8 * 64 (XCD runs); an element count that leaves many full windows
+    plus a partial tail window must still map every chunk exactly once."""
+    nelmt = 70001 if dim == 3 and nq <= 10 else (20011 if dim == 3 else 300007)
+    err = (_hex_case(sf, oracle, (nq,) * 3, nelmt, "auto", seed=nq) if dim == 3
+           else _quad_case(sf, oracle, (nq, nq), nelmt, "auto", seed=nq))
+    assert err <= TOL, (dim, nq, nelmt, err)
+
+
 def test_non_default_streams(sf, oracle, torch_mod):
     """`stream` is honoured: two launches on two streams, each synchronised on its own stream."""
     nq, nelmt = 8, 5000
