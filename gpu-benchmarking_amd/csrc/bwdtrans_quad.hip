@@ -116,14 +116,15 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
     }
 }
 
-// Orders for which SF_VARIANT_AUTO prefers the matrix-core kernel: nq 12..16 (346-353 vs 331-339 GDOF/s at
-// nq = 12, profiles/r01/tune_quad12_mfma2.log) and nq 25..32.  In between (17..24) the 16x16x4 tiles are
-// 30-45 % padding in each direction and the vector-ALU kernel with scalar-register basis operands is ahead
-// (306-329 vs 207-282 GDOF/s, profiles/r01/tune_quad*_scol2.log); on MI355X the fp64 matrix and vector pipes
-// have the same peak, so the exact-size FMAs win wherever their operands can be fed.
+// Orders for which SF_VARIANT_AUTO prefers the matrix-core kernel: nq >= 25.  On MI355X the fp64 matrix and vector
+// pipes have the same peak, so the exact-size FMAs of the wave kernel win wherever their operands can be fed; with
+// scalar-register basis blocks, four-element chunks and XCD runs that is every order up to 24 (349 / 355 / 358 / 359 /
+// 366 GDOF/s at nq = 12 .. 16 against 344 / 341 / 341 / 336 / 347 on the matrix cores,
+// profiles/r01/tune_quad1[2-6]_xcd_runs.log; 290-351 against 207-282 at nq = 17 .. 24).  From nq = 25 one pencil pass
+// per wave can no longer hide the scalar-load latency and the (padded) 16x16x4 tiles are ahead.
 bool quad_prefers_mfma(unsigned nq)
 {
-    return (nq >= 12 && nq <= 16) || nq >= 25;
+    return nq >= 25;
 }
 
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

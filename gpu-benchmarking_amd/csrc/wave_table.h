@@ -54,11 +54,11 @@ SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, XG64); // 336 / 331
 SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 12);
 SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 336 / 329
 SF_QUAD_CFG(11, 10,  4, BASIS_SMEM_COLS, 1, 1, OUT_LDS, XG64 | 12); // 316 (LDS copy of the basis: 297)
-SF_QUAD_CFG(12, 10,  4, BASIS_LDS,  1, 1, OUT_LDS, XG64);  // 339 / 331
-SF_QUAD_CFG(13, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64 | 12); // 342 (LDS basis: 287; matrix-core kernel: 349)
-SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);  // 345 (295; 355)
-SF_QUAD_CFG(15, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64);  // 334 (283; 359)
-SF_QUAD_CFG(16, 8,   4, BASIS_SMEM_COLS16, 1, 1, OUT_LDS, XG64);  // 330 (302; 358)
+SF_QUAD_CFG(12, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 349 (matrix-core kernel with XCD runs: 344)
+SF_QUAD_CFG(13, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64 | 12); // 355 (341)
+SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 358 (341)
+SF_QUAD_CFG(15, 4,   8, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64 | 12); // 359 (336)
+SF_QUAD_CFG(16, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 366 (347)
 // nq 17..24: vector-ALU kernel with column-blocked scalar operands (16 columns per SGPR ring): the padded
 // 16x16x4 matrix-core tiles need more pipe cycles here than the exact-size FMAs (profiles/r01/tune_quad*_scol2.log)
 SF_QUAD_CFG(17, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS,  XG64); // 328 (matrix-core kernel: 282); 3 elements fill 48-51 of the 64 lanes

@@ -93,15 +93,16 @@ void hex_case(const HexArgs &a)
         [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF>(a, 0); });
 }
 
-template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT>
+template <int NQ, int EC, int WPB, int BM, int MW, int KM, int OUT, int MEMF = 0>
 void quad_case(const QuadArgs &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "quad nq%d EC%d WPB%d %s MW%d K%d %s", NQ, EC, WPB,
-                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM, out_name(OUT));
+    std::snprintf(label, sizeof label, "quad nq%d EC%d WPB%d %s MW%d K%d %s mf%d", NQ, EC, WPB,
+                  BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM,
+                  out_name(OUT), MEMF);
     const double nm = NQ - 1;
     run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
-        a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT>(a, 0); });
+        a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF>(a, 0); });
 }
 
 template <int NQ, int EC, int WPB, int MW, int KM, bool OL = false> void quad_mfma_case(const QuadArgs &a)
@@ -164,6 +165,7 @@ int main(int argc, char **argv)
 #else
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
 #define Q(NQ, EC, WPB, BM, MW, KM, OUT) quad_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
+#define QM(NQ, EC, WPB, BM, MW, KM, OUT, MF) quad_case<NQ, EC, WPB, BM, MW, KM, OUT, MF>(a);
 #define M(NQ, EC, WPB, MW, KM) quad_mfma_case<NQ, EC, WPB, MW, KM>(a); quad_mfma_case<NQ, EC, WPB, MW, KM, true>(a);
     TUNE_CASES
 #endif

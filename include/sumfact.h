@@ -41,7 +41,7 @@ enum
 };
 
 /* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest known: 3D isotropic nq 2..11
- * WAVE, 12..16 MFMA; 2D isotropic nq 2..11 and 17..24 WAVE, 12..16 and 25..32 MFMA; anything else (anisotropic,
+ * WAVE, 12..16 MFMA; 2D isotropic nq 2..24 WAVE, 25..32 MFMA; anything else (anisotropic,
  * buffers not 16-byte aligned, higher orders) GENERIC. */
 enum
 {
