@@ -7,18 +7,31 @@
 A "step" is one pass of the hot path (one sf_bwdtrans_hex_f64 launch) over this rank's batch of
 elements, inputs resident in HBM.  The element batch is embarrassingly parallel: ranks own disjoint
 element ranges, there is NO data-path collective; torch.distributed (RCCL) carries only the barrier,
-the MAX of the elapsed time and the SUM of the result checksum.
+the MAX of the elapsed time, the SUM of the result checksum and the count of ranks.
+
+Launching.  One process per GPU.  Under a launcher (WORLD_SIZE set) `--gpus` must equal WORLD_SIZE or
+the run exits non-zero.  Without a launcher, `--gpus N` with N > 1 starts the N ranks itself
+(`python -m torch.distributed.run` as a child process, before this process makes any GPU call) and
+exits with the child's code; it refuses when the box has fewer than N GPUs.  `n_gpus` in the JSON line
+is the number of ranks the collectives actually reduced over, never the flag.
+
+Workload.  N = 1: 1 048 576 elements (BASELINE configs[2], the config the metric's target is quoted
+on).  N > 1: BASELINE configs[4], a 10 000 000-element batch sharded over the ranks ("strong"); rank 0
+then times the SAME batch alone on its GPU (it fits: 68 GB) for `speedup_vs_1gpu_same_batch`.
+`--elements-per-gpu` selects weak scaling instead.
 
 Metric (BASELINE.json): GDOF/s = 1e-9 * nelmt * nm^3 / t   (benchmark05/benchmark05.cc:1408; DOF =
 input modes).  Roofline: HBM, algorithmic bytes 8*(nm^3 + nq^3) per element.
 
 Rank 0 prints ONE JSON line.  Extra keys: "roofline", "cpu_baseline" (oracle port timed on this
-box's host cores, N=1 only) and "extra" (nq sweep 2..10 and the 2D quad nq=8 config, N=1 only).
+box's host cores, N=1 only) and "extra" (nq sweep 2..10 and the 2D quad orders, N=1 only).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,23 +42,79 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X datasheet HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NQ = 8
 GOLDEN_NORM_1M = 17134.76235  # benchmark05/nq8x8x8.log:45 (nelmt 1 048 576, sin/cos data)
+CONFIG4_ELEMENTS = 10_000_000  # BASELINE.json configs[4]
+QUAD_ORDERS = (2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32)  # benchmark04/run.sh:5-6 + 20 / 24 / 28
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="number of ranks = GPUs (default: WORLD_SIZE under a launcher, else 1)")
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--elements-per-gpu", type=int, default=1 << 20,
-                    help="weak scaling: elements owned by each rank (default 1 048 576)")
+    ap.add_argument("--elements-per-gpu", type=int, default=0,
+                    help="weak scaling: elements owned by each rank (N = 1 default: 1 048 576)")
     ap.add_argument("--total-elements", type=int, default=0,
                     help="strong scaling: shard this many elements over the ranks "
-                         "(e.g. 10000000 for BASELINE config 4)")
+                         "(N > 1 default: 10 000 000 = BASELINE config 4)")
     ap.add_argument("--nq", type=int, default=NQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-single-gpu-reference", action="store_true",
+                    help="N > 1, strong scaling: skip rank 0's solo run of the same batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def resolve_world(args, environ):
+    """(world, must_spawn).  Raises SystemExit when --gpus contradicts the launcher."""
+    env_world = environ.get("WORLD_SIZE")
+    if env_world is None:
+        n = 1 if args.gpus is None else args.gpus
+        if n < 1:
+            raise SystemExit(f"bench.py: --gpus {n} is not a rank count")
+        return n, n > 1
+    world = int(env_world)
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         "refusing to report a number for a different GPU count")
+    return world, False
+
+
+def pick_workload(args, world):
+    """(scaling, total elements, elements per rank or None)."""
+    if args.total_elements > 0 and args.elements_per_gpu > 0:
+        raise SystemExit("bench.py: give --total-elements or --elements-per-gpu, not both")
+    if args.total_elements > 0:
+        return "strong", args.total_elements, None
+    if args.elements_per_gpu > 0:
+        return "weak", world * args.elements_per_gpu, args.elements_per_gpu
+    if world == 1:
+        return "weak", 1 << 20, 1 << 20
+    return "strong", CONFIG4_ELEMENTS, None
+
+
+def spawn_ranks(n, argv):
+    """No launcher: start the N ranks as a child `torch.distributed.run`.  This process has made no
+    GPU call (device_count() does not initialise the runtime on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but this box has {have} GPU(s); one rank per GPU "
+                         "(set SF_BENCH_BACKEND=gloo to rehearse with ranks sharing a GPU)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    passed = [a for a in argv]
+    if not any(a == "--gpus" or a.startswith("--gpus=") for a in passed):
+        passed += ["--gpus", str(n)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd + passed, env=env)
 
 
 def time_steps(fn, steps, warmup, torch, dist, world):
@@ -73,37 +142,69 @@ def time_steps(fn, steps, warmup, torch, dist, world):
 
 
 def cpu_baseline(nq, seconds):
-    """Oracle (-O3/AVX2/FMA build, OpenMP over elements) on a bounded sample of the same workload."""
+    """Oracle (-O3/AVX2/FMA build, OpenMP over elements, register-blocked sweeps) on the full 1 Mi-element
+    batch of the headline config, bounded by `seconds` of CPU work."""
     import oracle
     nm = nq - 1
-    sample = 262144
+    sample = 1 << 20
     cores = oracle.usable_cpus()      # not omp_get_max_threads(): the box grants a CPU share
     for fast in (False, True):
         oracle.set_threads(cores, fast=fast)
     b = oracle.fill_basis(nm, nq)
     x = oracle.fill_random(sample * nm ** 3, 0x5F3759DF)
+    form = "blocked" if oracle.has_blocked(nq) else "vector"
     best, spent, reps = float("inf"), 0.0, 0
-    while reps < 3 or (spent < seconds and reps < 200):
+    while reps < 2 or (spent < seconds and reps < 200):
         t0 = time.perf_counter()
-        oracle.bwdtrans_hex((nq,) * 3, sample, b, b, b, x, form="vector", fast=True)
+        oracle.bwdtrans_hex((nq,) * 3, sample, b, b, b, x, form=form, fast=True)
         dt = time.perf_counter() - t0
         best = min(best, dt)
         spent += dt
         reps += 1
+    flops = 2.0 * (nq * nm ** 3 + nq ** 2 * nm ** 2 + nq ** 3 * nm) * sample / best
     return {"value": round(1e-9 * sample * nm ** 3 / best, 4), "unit": "GDOF/s",
             "cores": oracle.max_threads(fast=True), "kind": "port",
-            "sample": f"hex nq={nq}, {sample} elements, seeded random data, min of {reps} passes "
-                      f"({spent:.1f} s of CPU work), oracle/bwdtrans_ref.c 3-sweep form in CPU loop order (oracle_bwdtrans_hex_vector), "
-                      f"-O3 -mavx2 -mfma, OpenMP"}
+            "gflop_s": round(flops * 1e-9, 1),
+            "sample": f"hex nq={nq}, {sample} elements (the full headline batch), seeded random data, min of "
+                      f"{reps} passes ({spent:.1f} s of CPU work), oracle/bwdtrans_ref.c "
+                      f"oracle_bwdtrans_hex_{form} (3-sweep form, "
+                      f"{'register-blocked AVX2 i-vectors' if form == 'blocked' else 'CPU loop order'}), "
+                      f"-O3 -mavx2 -mfma, OpenMP over elements, {cores} threads granted"}
+
+
+def single_gpu_reference(sf, torch, dev, nq, total, steps):
+    """Rank 0 alone over the whole strong-scaling batch (fits one 288 GB GPU): GDOF/s, or None."""
+    nm = nq - 1
+    need = 8 * total * (nm ** 3 + nq ** 3)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if need > 0.92 * free:
+        return None
+    b = sf.fill_basis(nm, nq, dev)
+    x = sf.fill_random(total * nm ** 3, 0x5F3759DF, 0, dev)
+    out = torch.empty(total * nq ** 3, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        sf.bwdtrans_hex((nq,) * 3, b, b, b, x, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sf.bwdtrans_hex((nq,) * 3, b, b, b, x, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del x, out
+    torch.cuda.empty_cache()
+    return 1e-9 * total * nm ** 3 * steps / dt
 
 
 def main():
     args = parse()
+    world, must_spawn = resolve_world(args, os.environ)
+    if must_spawn:
+        sys.exit(spawn_ranks(world, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -111,7 +212,10 @@ def main():
     # one process per GPU; SF_BENCH_BACKEND=gloo (rehearsal: several ranks may then share a GPU,
     # the scalar reductions go through CPU tensors) -- default nccl = RCCL over xGMI
     backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s): one rank per GPU")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rdev = dev if backend == "nccl" else torch.device("cpu")   # where the reduced scalars live
@@ -125,12 +229,11 @@ def main():
     from gpu_benchmarking_amd import shard
 
     nq, nm = args.nq, args.nq - 1
-    if args.total_elements > 0:
-        lo, hi = shard.element_range(args.total_elements, world, rank)
-        scaling, total = "strong", args.total_elements
+    scaling, total, per_gpu = pick_workload(args, world)
+    if per_gpu is None:
+        lo, hi = shard.element_range(total, world, rank)
     else:
-        lo, hi = rank * args.elements_per_gpu, (rank + 1) * args.elements_per_gpu
-        scaling, total = "weak", world * args.elements_per_gpu
+        lo, hi = rank * per_gpu, (rank + 1) * per_gpu
     nelmt = hi - lo
 
     b = sf.fill_basis(nm, nq, dev)
@@ -144,38 +247,74 @@ def main():
 
     wall, evs = time_steps(step, args.steps, args.warmup, torch, dist, world)
     tmax = torch.tensor([wall, evs], dtype=torch.float64, device=rdev)
-    checksum = torch.tensor([sf.sumsq(out)], dtype=torch.float64, device=rdev)
+    # checksum, rank count and element count all come out of the same SUM all-reduce
+    sums = torch.tensor([sf.sumsq(out), 1.0, float(nelmt)], dtype=torch.float64, device=rdev)
+    mine = torch.tensor([float(nelmt), evs], dtype=torch.float64, device=rdev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(checksum, op=dist.ReduceOp.SUM)
-    wall_max, ev_max = float(tmax[0]), float(tmax[1])
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    wall_max = float(tmax[0])
+    ranks_reduced, elements_reduced = int(round(float(sums[1]))), int(round(float(sums[2])))
+    if ranks_reduced != world or elements_reduced != total:
+        raise SystemExit(f"bench.py: collectives reduced over {ranks_reduced} ranks / {elements_reduced} "
+                         f"elements, expected {world} / {total}")
+    del x, out
 
     result = None
+    bytes_per_elmt = 8 * (nm ** 3 + nq ** 3)
     if rank == 0:
         dof = total * nm ** 3
-        bytes_per_elmt = 8 * (nm ** 3 + nq ** 3)
-        kernel_s = ev_max / args.steps                 # average launch duration (HIP events)
-        achieved = nelmt * bytes_per_elmt / kernel_s * 1e-9   # GB/s of ONE GPU's launch
+        # per GPU: algorithmic bytes of ITS launch / ITS average launch duration (HIP events on the launch stream)
+        per_gpu_gbs = [float(p[0]) * bytes_per_elmt / (float(p[1]) / args.steps) * 1e-9 for p in per_rank]
+        slowest = min(range(world), key=lambda r: per_gpu_gbs[r])
+        achieved = per_gpu_gbs[slowest]
+        kernel_s = float(per_rank[slowest][1]) / args.steps
+        traffic = shard.recorded_traffic(ROOT, 3, nq, int(per_rank[slowest][0]))
         result = {
             "metric": "GDOF/s for 3D hex sum-factorisation, fp64, nq=2..10 sweep",
+            "metric_detail": f"value = the nq={nq} order (the one north_star's target is quoted on); the "
+                             "per-order sweep 2..10 is in extra.hex_sweep, its min / geomean in roofline",
             "value": round(1e-9 * dof * args.steps / wall_max, 3),
             "unit": "GDOF/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ranks_reduced, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * wall_max / args.steps, 5),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"benchmark05 3D hex BwdTrans nq={nq}x{nq}x{nq}, "
-                                   f"{nelmt} elements per GPU ({total} total), fp64, "
-                                   f"seeded random modes, cos basis",
+                                   f"{total} elements over {world} GPU(s) ({nelmt} on rank 0), fp64, "
+                                   f"seeded random modes, cos basis"
+                                   + (" [BASELINE configs[4]]" if total == CONFIG4_ELEMENTS and world > 1 else ""),
                        "nq": nq, "elements_per_gpu": nelmt, "total_elements": total,
-                       "parallelism": f"element-range sharding x{world}, no data-path collective"},
+                       "parallelism": f"element-range sharding x{world}, no data-path collective",
+                       "backend": "rccl" if backend == "nccl" else backend},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": shard.recorded_traffic(ROOT, nq, nelmt),
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else
+                         "not recorded for this shape (PMC passes are separate rocprofv3 runs, profiles/README.md)",
+                         "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
                          "kernel": "sf::hex_wave_kernel", "bytes_per_element": bytes_per_elmt,
                          "kernel_ms": round(kernel_s * 1e3, 5)},
-            "checksum_norm": math.sqrt(float(checksum[0])),
+            "checksum_norm": math.sqrt(float(sums[0])),
         }
+        if world > 1:
+            result["roofline"]["per_gpu_frac"] = [round(g / HBM_PEAK_GBS, 4) for g in per_gpu_gbs]
+            result["roofline"]["note"] = "achieved / frac are the slowest GPU's launch"
+            if backend != "nccl":
+                result["rehearsal"] = f"backend {backend}: ranks may share a GPU; not a scaling measurement"
+
+    if world > 1 and scaling == "strong" and not args.no_single_gpu_reference:
+        # rank 0 alone over the same batch, the others wait at the barrier
+        if rank == 0:
+            solo = single_gpu_reference(sf, torch, dev, nq, total, max(2, min(args.steps, 10)))
+            if solo:
+                result["single_gpu_same_batch_gdof_s"] = round(solo, 3)
+                result["speedup_vs_1gpu_same_batch"] = round(result["value"] / solo, 3)
+        dist.barrier()
 
     if rank == 0 and world == 1:
         # parity sanity on the reference's own data: golden norm of benchmark05/nq8x8x8.log:45
@@ -188,6 +327,11 @@ def main():
             del xs, os_
         if not args.no_extra:
             result["extra"] = extras(sf, torch, dev)
+            fr = [v["frac"] for v in result["extra"]["hex_sweep"].values()]
+            worst = min(result["extra"]["hex_sweep"].items(), key=lambda kv: kv[1]["frac"])
+            result["roofline"]["sweep_min"] = round(min(fr), 4)
+            result["roofline"]["sweep_min_nq"] = int(worst[0])
+            result["roofline"]["sweep_geomean"] = round(math.exp(sum(math.log(f) for f in fr) / len(fr)), 4)
             # second denominator: the device's own measured stream rate (benchmark02's x += y,
             # 24 B/element), next to the 8 TB/s datasheet figure
             stream = measured_stream_gbs(sf, torch, dev)
@@ -223,9 +367,10 @@ def measured_stream_gbs(sf, torch, dev, n=1 << 28, reps=10):
     return 24.0 * n / best * 1e-6
 
 
-def extras(sf, torch, dev, nelmt=1 << 20, reps=10):
-    """BASELINE configs 1 and 3 on one GPU: quad nq=8 and the hex nq = 2..10 sweep (min of reps,
-    HIP events), each with its fraction of the 8 TB/s HBM roofline."""
+def extras(sf, torch, dev, nelmt=1 << 20, reps=40):
+    """BASELINE configs 1 and 3 on one GPU: the hex nq = 2..10 sweep and the quad orders of the reference's
+    run.sh (+ 20 / 24 / 28), min of `reps` groups (the reference's n_tests = 40; HIP events), each with its
+    fraction of the 8 TB/s HBM roofline."""
     def best_ms(fn, inner=8):
         # `inner` back-to-back launches per event pair, replayed from a HIP graph when capture works: the
         # low orders run for ~10 us, where eager launches mostly measure the host's launch cadence
@@ -275,7 +420,7 @@ def extras(sf, torch, dev, nelmt=1 << 20, reps=10):
         out["hex_sweep"][str(nq)] = {"gdof_s": round(nelmt * nm ** 3 / ms * 1e-6, 2),
                                      "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         del x, o
-    for nq in (8, 16, 20, 24, 32):  # 20 / 24: vector-ALU kernel past the crossover; 16 / 32: matrix cores
+    for nq in QUAD_ORDERS:
         nm = nq - 1
         b = sf.fill_basis(nm, nq, dev)
         x = sf.fill_random(nelmt * nm ** 2, 1, 0, dev)

@@ -34,9 +34,25 @@ def aggregate_gdofs(total_elements, nm_tot, steps, max_elapsed_s):
     return 1e-9 * total_elements * nm_tot * steps / max_elapsed_s
 
 
-def recorded_traffic(root, nq, nelmt):
+KERNEL_SOURCES = ("bwdtrans_wave.h", "wave_table.h", "bwdtrans_hex.hip", "bwdtrans_quad.hip",
+                  "bwdtrans_mfma.h", "sf_common.h", "wave_launch.h")
+
+
+def kernel_source_hash(root):
+    """sha256 (16 hex digits) over the kernel sources a PMC record describes; a record whose hash differs
+    from the tree's was taken on other code and is reported as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(root, "gpu-benchmarking_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(root, dim, nq, nelmt):
     """HBM bytes per launch from the PMC passes committed under profiles/ (None if not recorded for
-    this shape).  bench.py cannot collect PMC counters itself; see profiles/README.md."""
+    this shape).  bench.py cannot collect PMC counters itself (gpurun keeps --pmc runs separate from
+    every other trace); see profiles/README.md.  Returns {"bytes", "over_algorithmic", "source"}."""
     path = os.path.join(root, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
@@ -44,6 +60,12 @@ def recorded_traffic(root, nq, nelmt):
     except (OSError, ValueError):
         return None
     for row in rec.get("rows", []):
-        if row.get("nq") == nq and row.get("nelmt") == nelmt and row.get("dim", 3) == 3:
-            return row.get("hbm_bytes_per_launch")
+        if row.get("nq") == nq and row.get("nelmt") == nelmt and row.get("dim", 3) == dim:
+            stale = row.get("kernel_source_hash") != kernel_source_hash(root)
+            return {"bytes": row.get("hbm_bytes_per_launch"),
+                    "over_algorithmic": row.get("traffic_over_algorithmic"),
+                    "source": "recorded: profiles/hbm_traffic.json, rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + "
+                              f"WRITE_SIZE in separate passes, round {row.get('round', rec.get('round'))}"
+                              + (" -- STALE: the kernel sources changed since that pass" if stale else
+                                 ", same kernel sources as this tree")}
     return None

@@ -4,6 +4,7 @@
 // GDOF/s (min and mean), algorithmic GB/s (8*(nm^d+nq^d) B/element) and sqrt(sum out^2) as a sanity value.
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
+#include "tune_guard.h"
 
 #include <algorithm>
 #include <cmath>
@@ -88,6 +89,9 @@ void hex_case(const HexArgs &a)
                   MW, KM, out_name(OUT),
                   (MEMF & 12) == 12 ? " al-io" : ((MEMF & 12) == 8 ? " al-o" : ((MEMF & 12) == 4 ? " al-i" : "")), xg);
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
         [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF>(a, 0); });
@@ -101,6 +105,9 @@ void quad_case(const QuadArgs &a)
                   BM == BASIS_LDS ? "lds " : (BM == BASIS_SMEM ? "smem" : (BM == BASIS_SMEM_COLS ? "sc8 " : "sc16")), MW, KM,
                   out_name(OUT), MEMF);
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 2), sizeof(double) * a.nelmt * tune::ipow(NQ, 2),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF>(a, 0); });
 }
@@ -111,6 +118,9 @@ template <int NQ, int EC, int WPB, int MW, int KM, bool OL = false> void quad_mf
     std::snprintf(label, sizeof label, "quad nq%d MFMA EC%d WPB%d MW%d K%d %s", NQ, EC, WPB, MW, KM,
                   OL ? "lds" : "st8");
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 2), sizeof(double) * a.nelmt * tune::ipow(NQ, 2),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm, a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_mfma<NQ, EC, WPB, MW, KM, OL>(a, 0); });
 }
@@ -120,6 +130,9 @@ template <int NQ, int EC, int WPB, int MW, int KM> void hex_mfma_case(const HexA
     char label[96];
     std::snprintf(label, sizeof label, "hex nq%d MFMA EC%d WPB%d MW%d K%d", NQ, EC, WPB, MW, KM);
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma<NQ, EC, WPB, MW, KM>(a, 0); });
 }
@@ -149,6 +162,7 @@ int main(int argc, char **argv)
     CK(hipMalloc((void **)&b2, sizeof(double) * nm * nq));
     CK(hipMalloc((void **)&in, sizeof(double) * nin));
     CK(hipMalloc((void **)&out, sizeof(double) * nout));
+    tune::capacity() = {sizeof(double) * nin, sizeof(double) * nout, sizeof(double) * nm * nq};
     fill_basis(b0, nm, nq, 0);
     fill_basis(b1, nm, nq, 0);
     fill_basis(b2, nm, nq, 0);

@@ -1,6 +1,7 @@
 // sf_tune_f32.hip -- configuration sweep of the T = float instantiations (development tool).
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
+#include "tune_guard.h"
 
 #include <algorithm>
 #include <cmath>
@@ -65,6 +66,9 @@ void hex_case(const HexArgsT<float> &a)
     std::snprintf(label, sizeof label, "hex f32 nq%d EC%d WPB%d %s MW%d K%d o%d mf%d", NQ, EC, WPB,
                   BM == BASIS_LDS ? "lds " : "smem", MW, KM, OUT, MEMF);
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(float) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(float) * a.nelmt * tune::ipow(NQ, 3),
+                    sizeof(float) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 4.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ * NQ,
         [&]() { return launch_hex_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF, float>(a, 0); });
@@ -77,6 +81,9 @@ void quad_case(const QuadArgsT<float> &a)
     std::snprintf(label, sizeof label, "quad f32 nq%d EC%d WPB%d bm%d MW%d K%d o%d mf%d", NQ, EC, WPB, BM, MW, KM, OUT,
                   MEMF);
     const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(float) * a.nelmt * tune::ipow(NQ - 1, 2), sizeof(float) * a.nelmt * tune::ipow(NQ, 2),
+                    sizeof(float) * (NQ - 1) * NQ))
+        return;
     run(label, a.nelmt * nm * nm, a.nelmt * 4.0 * (nm * nm + (double)NQ * NQ), a.out,
         a.nelmt * (size_t)NQ * NQ,
         [&]() { return launch_quad_wave<NQ, EC, WPB, BM, MW, KM, OUT, MEMF, float>(a, 0); });
@@ -89,12 +96,16 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&g_e0));
     CK(hipEventCreate(&g_e1));
     constexpr int NQ = 8, NM = 7;
+    // buffers hold the LARGEST case below: hex nq 8 (343 in / 512 out per element) and quad nq 24 (529 / 576)
+    constexpr size_t kMaxIn = 529, kMaxOut = 576, kMaxBasis = 23 * 24;
+    static_assert(kMaxIn >= NM * NM * NM && kMaxOut >= NQ * NQ * NQ, "hex nq 8 must fit");
     float *b, *in, *out;
     CK(hipMalloc((void **)&b, sizeof(float) * NM * NQ));
-    CK(hipMalloc((void **)&in, sizeof(float) * nelmt * NM * NM * NM));
-    CK(hipMalloc((void **)&out, sizeof(float) * nelmt * NQ * NQ * NQ));
+    CK(hipMalloc((void **)&in, sizeof(float) * nelmt * kMaxIn));
+    CK(hipMalloc((void **)&out, sizeof(float) * nelmt * kMaxOut));
+    tune::capacity() = {sizeof(float) * nelmt * kMaxIn, sizeof(float) * nelmt * kMaxOut, sizeof(float) * kMaxBasis};
     fill_basis_f32(b, NM, NQ, 0);
-    fill_random_f32(in, nelmt * NM * NM * NM, 0x5F3759DF, 0, 0);
+    fill_random_f32(in, nelmt * kMaxIn, 0x5F3759DF, 0, 0);
     CK(hipDeviceSynchronize());
     HexArgsT<float> h{b, b, b, in, nullptr, out, nelmt};
     for (int rep = 0; rep < 2; ++rep)
@@ -113,11 +124,12 @@ int main(int argc, char **argv)
     quad_case<8, 16, 4, BASIS_SMEM, 4, 1>(q);
     // nq 15 / 16: the derived rows (16 elements per chunk) leave 8 waves per CU; smaller chunks
     float *b2;
-    CK(hipMalloc((void **)&b2, sizeof(float) * 16 * 16));
+    CK(hipMalloc((void **)&b2, sizeof(float) * kMaxBasis));
     for (int rep = 0; rep < 2; ++rep)
     {
 #define ROW(NQ, MF)                                                                                \
     {                                                                                              \
+        static_assert((NQ - 1) * NQ <= kMaxBasis, "basis buffer");                                 \
         fill_basis_f32(b2, NQ - 1, NQ, 0);                                                         \
         QuadArgsT<float> qq{b2, b2, in, nullptr, out, nelmt};                                      \
         quad_case<NQ, 16, 4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, MF>(qq);                            \

@@ -5,6 +5,7 @@
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 #include "../csrc/wave_table.h"
+#include "tune_guard.h"
 
 #include <algorithm>
 #include <cmath>
@@ -73,6 +74,9 @@ template <int NQ, int MF> static void hex_one()
                   C::KM, MF);
     const double nm = NQ - 1;
     HexArgs a{g_b, g_b, g_b, g_in, nullptr, g_out, g_nelmt};
+    if (!tune::fits(label, sizeof(double) * g_nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * g_nelmt * tune::ipow(NQ, 3),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, g_nelmt * nm * nm * nm, g_nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ),
         g_nelmt * (size_t)NQ * NQ * NQ,
         [&]() { return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF>(a, 0); });
@@ -86,6 +90,9 @@ template <int NQ, int MF> static void quad_one()
                   C::KM, MF);
     const double nm = NQ - 1;
     QuadArgs a{g_b, g_b, g_in, nullptr, g_out, g_nelmt};
+    if (!tune::fits(label, sizeof(double) * g_nelmt * tune::ipow(NQ - 1, 2), sizeof(double) * g_nelmt * tune::ipow(NQ, 2),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, g_nelmt * nm * nm, g_nelmt * 8.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
         [&]() { return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF>(a, 0); });
 }
@@ -96,6 +103,9 @@ template <int NQ, bool OL, int MW = 1, int XG = 0> static void quad_mfma_one()
     std::snprintf(label, sizeof label, "quad nq%-2d MFMA EC2 WPB4 MW%d %s xg%d", NQ, MW, OL ? "lds" : "st8", XG);
     const double nm = NQ - 1;
     QuadArgs a{g_b, g_b, g_in, nullptr, g_out, g_nelmt};
+    if (!tune::fits(label, sizeof(double) * g_nelmt * tune::ipow(NQ - 1, 2), sizeof(double) * g_nelmt * tune::ipow(NQ, 2),
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
     run(label, g_nelmt * nm * nm, g_nelmt * 8.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
         [&]() { return launch_quad_mfma<NQ, 2, 4, MW, (NQ <= 16 ? 1 : 2), OL, XG>(a, 0); });
 }
@@ -141,6 +151,9 @@ template <int NQ, int MF> static void hex_f32_one()
     const double nm = NQ - 1;
     const float *b  = (const float *)g_b;
     HexArgsT<float> a{b, b, b, (const float *)g_in, nullptr, (float *)g_out, g_nelmt};
+    if (!tune::fits(label, sizeof(float) * g_nelmt * tune::ipow(NQ - 1, 3), sizeof(float) * g_nelmt * tune::ipow(NQ, 3),
+                    sizeof(float) * (NQ - 1) * NQ))
+        return;
     run_f32(label, g_nelmt * nm * nm * nm, g_nelmt * 4.0 * (nm * nm * nm + (double)NQ * NQ * NQ),
             g_nelmt * (size_t)NQ * NQ * NQ, [&]() {
                 return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF, float>(a, 0);
@@ -155,6 +168,9 @@ template <int NQ, int MF> static void quad_f32_one()
     const double nm = NQ - 1;
     const float *b  = (const float *)g_b;
     QuadArgsT<float> a{b, b, (const float *)g_in, nullptr, (float *)g_out, g_nelmt};
+    if (!tune::fits(label, sizeof(float) * g_nelmt * tune::ipow(NQ - 1, 2), sizeof(float) * g_nelmt * tune::ipow(NQ, 2),
+                    sizeof(float) * (NQ - 1) * NQ))
+        return;
     run_f32(label, g_nelmt * nm * nm, g_nelmt * 4.0 * (nm * nm + (double)NQ * NQ), g_nelmt * (size_t)NQ * NQ,
             [&]() {
                 return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, MF, float>(a, 0);
@@ -248,8 +264,9 @@ int main(int argc, char **argv)
     CK(hipGetDeviceProperties(&prop, 0));
     std::printf("device: %s, %d CUs, nelmt %zu reps %d\n", prop.gcnArchName, prop.multiProcessorCount,
                 g_nelmt, g_reps);
-    // buffers sized for the largest row (hex nq = 10 / quad nq = 32)
-    const size_t nin = g_nelmt * 961, nout = g_nelmt * 1024;
+    // buffers sized for the largest row: hex nq = 11 (1000 in / 1331 out per element; quad nq = 32 needs 961 / 1024)
+    const size_t nin = g_nelmt * 1000, nout = g_nelmt * 1331;
+    tune::capacity() = {sizeof(double) * nin, sizeof(double) * nout, sizeof(double) * 32 * 32};
     CK(hipMalloc((void **)&g_b, sizeof(double) * 32 * 32));
     CK(hipMalloc((void **)&g_in, sizeof(double) * nin));
     CK(hipMalloc((void **)&g_out, sizeof(double) * nout));

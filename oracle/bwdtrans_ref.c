@@ -422,6 +422,164 @@ int oracle_bwdtrans_hex_vector(unsigned nq0, unsigned nq1, unsigned nq2, size_t 
     return fail ? -2 : 0;
 }
 
+/*
+ * Register-blocked form of the same three sweeps for isotropic nq = 2..10 -- the timed CPU baseline
+ * (bench.py cpu_baseline, kind "port").  The i direction is held in 4-wide vectors (AVX2 ymm under
+ * -mavx2; rows padded to NQP = 4*ceil(nq/4) against zero basis columns), four (r,q) pencils / four j /
+ * four k share every basis or intermediate vector they load, and all extents are compile-time constants,
+ * so the loops unroll into straight FMA chains.  Every output is still the ascending-p / ascending-q /
+ * ascending-r sum starting from 0.0 of benchmark05.cc:361-423: without FMA contraction (liboracle.so)
+ * the result is bit-identical to oracle_bwdtrans_hex_sweeps (tests/test_oracle_golden.py).
+ */
+typedef double v4d __attribute__((vector_size(32), aligned(8)));
+#define HB_MAXQ 10
+#define HB_MAXP 12
+
+#define HB_INLINE static inline __attribute__((always_inline))
+
+/* dir 0, NB consecutive (r,q) rows: w1[rq][i] = sum_p in[rq][p] * B0[p][i] */
+HB_INLINE void hb_dir0(const int NM, const int NV, const int NB, const double *restrict b0p,
+                       const double *restrict src, double *restrict dst)
+{
+    const int NQP = 4 * NV;
+    v4d acc[4][(HB_MAXP / 4)];
+    for (int t = 0; t < NB; ++t)
+        for (int v = 0; v < NV; ++v)
+            acc[t][v] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < NM; ++p)
+        for (int v = 0; v < NV; ++v)
+        {
+            const v4d b = *(const v4d *)(b0p + p * NQP + 4 * v);
+            for (int t = 0; t < NB; ++t)
+            {
+                const double u = src[t * NM + p];
+                acc[t][v] += (v4d){u, u, u, u} * b;
+            }
+        }
+    for (int t = 0; t < NB; ++t)
+        for (int v = 0; v < NV; ++v)
+            *(v4d *)(dst + t * NQP + 4 * v) = acc[t][v];
+}
+
+/* dirs 1 and 2, NB consecutive output columns c: dst_c[i] = sum_m src[m*SS + i] * B[m*NQ + c]; PADDED: rows of
+ * NQP doubles (intermediate) or NQ doubles (final output, tail written scalar by scalar) DS apart */
+HB_INLINE void hb_dir12(const int NM, const int NQ, const int NV, const int NB, const int SS, const int DS,
+                        const int PADDED, const double *restrict bas, const double *restrict src,
+                        double *restrict dst)
+{
+    v4d acc[4][(HB_MAXP / 4)];
+    for (int t = 0; t < NB; ++t)
+        for (int v = 0; v < NV; ++v)
+            acc[t][v] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < NM; ++m)
+        for (int v = 0; v < NV; ++v)
+        {
+            const v4d s = *(const v4d *)(src + m * SS + 4 * v);
+            for (int t = 0; t < NB; ++t)
+            {
+                const double b = bas[m * NQ + t];
+                acc[t][v] += s * (v4d){b, b, b, b};
+            }
+        }
+    for (int t = 0; t < NB; ++t)
+        for (int v = 0; v < NV; ++v)
+        {
+            if (PADDED || 4 * v + 4 <= NQ)
+                *(v4d *)(dst + t * DS + 4 * v) = acc[t][v];
+            else
+                for (int x = 0; 4 * v + x < NQ; ++x)
+                    dst[t * DS + 4 * v + x] = acc[t][v][x];
+        }
+}
+
+HB_INLINE void hex_blocked_element(const int NQ, const double *restrict b0p, const double *restrict b1,
+                                   const double *restrict b2, const double *restrict ine,
+                                   double *restrict oute)
+{
+    const int NM = NQ - 1, NV = (NQ + 3) / 4, NQP = 4 * NV;
+    double w1[(HB_MAXQ - 1) * (HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(32)));
+    double w2[(HB_MAXQ - 1) * HB_MAXQ * HB_MAXP] __attribute__((aligned(32)));
+    /* dir 0: w1[r][q][i], four (r,q) rows per pass */
+    {
+        const int NR = NM * NM, full = NR / 4 * 4;
+        for (int rq = 0; rq < full; rq += 4)
+            hb_dir0(NM, NV, 4, b0p, ine + rq * NM, w1 + rq * NQP);
+        if (NR - full)
+            hb_dir0(NM, NV, NR - full, b0p, ine + full * NM, w1 + full * NQP);
+    }
+    /* dir 1: w2[r][j][i] = sum_q w1[r][q][i] * B1[q][j], four j per pass */
+    for (int r = 0; r < NM; ++r)
+    {
+        const int full = NQ / 4 * 4;
+        for (int j = 0; j < full; j += 4)
+            hb_dir12(NM, NQ, NV, 4, NQP, NQP, 1, b1 + j, w1 + r * NM * NQP, w2 + (r * NQ + j) * NQP);
+        if (NQ - full)
+            hb_dir12(NM, NQ, NV, NQ - full, NQP, NQP, 1, b1 + full, w1 + r * NM * NQP,
+                     w2 + (r * NQ + full) * NQP);
+    }
+    /* dir 2: out[k][j][i] = sum_r w2[r][j][i] * B2[r][k], four k per pass */
+    for (int j = 0; j < NQ; ++j)
+    {
+        const int full = NQ / 4 * 4;
+        for (int k = 0; k < full; k += 4)
+            hb_dir12(NM, NQ, NV, 4, NQ * NQP, NQ * NQ, 0, b2 + k, w2 + j * NQP, oute + (k * NQ + j) * NQ);
+        if (NQ - full)
+            hb_dir12(NM, NQ, NV, NQ - full, NQ * NQP, NQ * NQ, 0, b2 + full, w2 + j * NQP,
+                     oute + (full * NQ + j) * NQ);
+    }
+}
+
+#define HB_INSTANCE(N)                                                                                        \
+    static void hex_blocked_##N(size_t nelmt, const double *b0p, const double *b1, const double *b2,          \
+                                const double *in, double *out)                                                \
+    {                                                                                                         \
+        const size_t nmt = (size_t)(N - 1) * (N - 1) * (N - 1), nqt = (size_t)N * N * N;                      \
+        _Pragma("omp parallel for schedule(static)") for (size_t e = 0; e < nelmt; ++e)                       \
+            hex_blocked_element(N, b0p, b1, b2, in + nmt * e, out + nqt * e);                                 \
+    }
+HB_INSTANCE(2)
+HB_INSTANCE(3)
+HB_INSTANCE(4)
+HB_INSTANCE(5)
+HB_INSTANCE(6)
+HB_INSTANCE(7)
+HB_INSTANCE(8)
+HB_INSTANCE(9)
+HB_INSTANCE(10)
+#undef HB_INSTANCE
+
+/* 1 when oracle_bwdtrans_hex_blocked is instantiated for these extents (isotropic nq 2..10) */
+int oracle_has_blocked(unsigned nq0, unsigned nq1, unsigned nq2)
+{
+    return nq0 == nq1 && nq1 == nq2 && nq0 >= 2 && nq0 <= HB_MAXQ;
+}
+
+int oracle_bwdtrans_hex_blocked(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt,
+                                const double *basis0, const double *basis1, const double *basis2,
+                                const double *in, double *out)
+{
+    if (!oracle_has_blocked(nq0, nq1, nq2))
+        return -1;
+    const unsigned nq = nq0, nm = nq - 1, nqp = (nq + 3) / 4 * 4;
+    double b0p[(HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(32)));
+    for (unsigned p = 0; p < nm; ++p)
+        for (unsigned i = 0; i < nqp; ++i)
+            b0p[p * nqp + i] = i < nq ? basis0[p * nq + i] : 0.0;
+    switch (nq)
+    {
+    case 2: hex_blocked_2(nelmt, b0p, basis1, basis2, in, out); break;
+    case 3: hex_blocked_3(nelmt, b0p, basis1, basis2, in, out); break;
+    case 4: hex_blocked_4(nelmt, b0p, basis1, basis2, in, out); break;
+    case 5: hex_blocked_5(nelmt, b0p, basis1, basis2, in, out); break;
+    case 6: hex_blocked_6(nelmt, b0p, basis1, basis2, in, out); break;
+    case 7: hex_blocked_7(nelmt, b0p, basis1, basis2, in, out); break;
+    case 8: hex_blocked_8(nelmt, b0p, basis1, basis2, in, out); break;
+    case 9: hex_blocked_9(nelmt, b0p, basis1, basis2, in, out); break;
+    default: hex_blocked_10(nelmt, b0p, basis1, basis2, in, out); break;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------- 2D quad --------------------- */
 
 /* Fused nest (benchmark04.cc:49-72): in[e][q][p] -> out[e][j][i]; scratch wsp[nm1]. */

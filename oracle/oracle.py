@@ -50,8 +50,10 @@ def _lib(fast=False):
         lib.oracle_matvec.argtypes = [sz, sz, _c_dp, _c_dp, _c_dp]
         lib.oracle_sumsq.argtypes = [_c_dp, sz]
         lib.oracle_sumsq.restype = dbl
+        lib.oracle_has_blocked.argtypes = [u32, u32, u32]
+        lib.oracle_has_blocked.restype = ctypes.c_int
         for name in ("oracle_bwdtrans_hex_fused", "oracle_bwdtrans_hex_sweeps",
-                     "oracle_bwdtrans_hex_vector"):
+                     "oracle_bwdtrans_hex_vector", "oracle_bwdtrans_hex_blocked"):
             f = getattr(lib, name)
             f.argtypes = [u32, u32, u32, sz, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]
             f.restype = ctypes.c_int
@@ -176,11 +178,19 @@ def sumsq(x, fast=False):
 
 # ---------------------------------------------------------------- BwdTrans ---------------------
 
-def bwdtrans_hex(nq, nelmt, b0, b1, b2, inp, form="sweeps", fast=False):
+def has_blocked(nq):
+    """True when the register-blocked form (the timed CPU baseline) exists for isotropic order nq."""
+    return bool(_lib().oracle_has_blocked(nq, nq, nq))
+
+
+def bwdtrans_hex(nq, nelmt, b0, b1, b2, inp, form="sweeps", fast=False, out=None):
     """3D hex BwdTrans.  form='fused' -> benchmark05.cc:57-101, 'sweeps' -> :361-423,
-    'vector' -> the same sweeps in a CPU-vectorisable loop order (the timed CPU baseline)."""
+    'vector' -> the same sweeps in a CPU-vectorisable loop order, 'blocked' -> the same sweeps
+    register-blocked over 4-wide i-vectors (isotropic nq 2..10; the timed CPU baseline)."""
     nq0, nq1, nq2 = nq
-    out = np.empty(nelmt * nq0 * nq1 * nq2, dtype=np.float64)
+    if out is None:     # a timing loop passes its own (already touched) buffer
+        out = np.empty(nelmt * nq0 * nq1 * nq2, dtype=np.float64)
+    assert out.size == nelmt * nq0 * nq1 * nq2
     f = getattr(_lib(fast), "oracle_bwdtrans_hex_" + form)
     rc = f(nq0, nq1, nq2, nelmt, _p(b0), _p(b1), _p(b2), _p(inp), _p(out))
     if rc != 0:

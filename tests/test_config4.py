@@ -1,0 +1,172 @@
+"""BASELINE configs[4]: benchmark05 3D hex nq = 8, 10 000 000 elements sharded over 8 GPUs.
+
+The reference is single-GPU (benchmark05/run.sh:7) and its 32-bit indexing cannot even address this batch
+(nelmt*nq^3 > 2^32, benchmark05/benchmark05.cc:94); the sharding is this build's.  An 8-GPU node is the
+driver's to launch, so on the one-GPU box the tests run (a) rank 7-of-8's shard exactly as bench.py would on
+that rank, against the oracle, and (b) the whole 10 M batch on one GPU (68 GB) against all eight shards run
+separately: the union of shard outputs must be bit-identical to the single-GPU output, and the reduced
+checksum must equal the single-GPU checksum.  CPU tests cover bench.py's launch rules (no GPU call involved).
+"""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOTAL, WORLD, NQ, NM = 10_000_000, 8, 8, 7
+SEED = 0x5F3759DF          # bench.py's seed
+NMT, NQT = NM ** 3, NQ ** 3
+
+
+@pytest.fixture(scope="module")
+def sf():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as ge
+    return ge.load_package()
+
+
+def _bench():
+    import importlib
+    return importlib.import_module("bench")
+
+
+# ---------------------------------------------------------------- CPU: launch rules ------------------------
+
+def test_gpus_flag_and_launcher_must_agree():
+    b = _bench()
+    assert b.resolve_world(b.parse([]), {}) == (1, False)
+    assert b.resolve_world(b.parse(["--gpus", "1"]), {}) == (1, False)
+    assert b.resolve_world(b.parse(["--gpus", "8"]), {}) == (8, True)          # no launcher: spawn 8 ranks
+    assert b.resolve_world(b.parse(["--gpus", "8"]), {"WORLD_SIZE": "8"}) == (8, False)
+    assert b.resolve_world(b.parse([]), {"WORLD_SIZE": "4"}) == (4, False)
+    with pytest.raises(SystemExit) as exc:                                     # never n_gpus: 1 for --gpus 8
+        b.resolve_world(b.parse(["--gpus", "8"]), {"WORLD_SIZE": "1"})
+    assert "WORLD_SIZE=1" in str(exc.value)
+    with pytest.raises(SystemExit):
+        b.resolve_world(b.parse(["--gpus", "2"]), {"WORLD_SIZE": "4"})
+    with pytest.raises(SystemExit):
+        b.resolve_world(b.parse(["--gpus", "0"]), {})
+
+
+def test_default_workloads():
+    b = _bench()
+    assert b.pick_workload(b.parse([]), 1) == ("weak", 1 << 20, 1 << 20)
+    for n in (2, 4, 8):                                                       # config 4 is the N > 1 default
+        assert b.pick_workload(b.parse([]), n) == ("strong", TOTAL, None)
+    assert b.pick_workload(b.parse(["--elements-per-gpu", "1000"]), 4) == ("weak", 4000, 1000)
+    assert b.pick_workload(b.parse(["--total-elements", "77"]), 2) == ("strong", 77, None)
+    with pytest.raises(SystemExit):
+        b.pick_workload(b.parse(["--total-elements", "7", "--elements-per-gpu", "7"]), 2)
+
+
+def test_mismatched_launch_exits_nonzero_without_touching_a_gpu():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr and not res.stdout.strip()
+
+
+def test_config4_shards_tile_the_batch():
+    import __graft_entry__ as ge
+    shard = ge.load_package().shard
+    r = shard.all_ranges(TOTAL, WORLD)
+    assert r[0][0] == 0 and r[-1][1] == TOTAL
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert {hi - lo for lo, hi in r} == {1_250_000}
+    assert shard.element_range(TOTAL, WORLD, 7) == (8_750_000, 10_000_000)
+
+
+# ---------------------------------------------------------------- GPU ---------------------------------------
+
+def _oracle_window(oracle, first_elmt, n):
+    b = oracle.fill_basis(NM, NQ)
+    x = oracle.fill_random(n * NMT, SEED, first_elmt * NMT)
+    return oracle.bwdtrans_hex((NQ,) * 3, n, b, b, b, x)
+
+
+@pytest.mark.gpu
+def test_rank7_of_8_shard_against_oracle(sf, oracle):
+    """What rank 7 of the 8-GPU job computes: elements [8 750 000, 10 000 000), generated from the global
+    counter; head / interior / tail windows element-wise against the oracle."""
+    lo, hi = sf.shard.element_range(TOTAL, WORLD, 7)
+    n = hi - lo
+    b = sf.fill_basis(NM, NQ)
+    x = sf.fill_random(n * NMT, SEED, lo * NMT)
+    out = sf.bwdtrans_hex((NQ,) * 3, b, b, b, x)
+    win = 257
+    for off in (0, 1, 524_287, 1_048_575, n - win):
+        ref = _oracle_window(oracle, lo + off, win)
+        got = out[off * NQT:(off + win) * NQT].cpu().numpy()
+        assert oracle.rel_err(got, ref) <= 1e-12, off
+    # the shard's input really is the slice of the global array (first values of element `lo`)
+    assert np.array_equal(x[:NMT].cpu().numpy(), oracle.fill_random(NMT, SEED, lo * NMT))
+
+
+@pytest.mark.gpu
+def test_full_10m_batch_on_one_gpu_equals_the_eight_shards(sf, oracle):
+    """Strong-scaling identity at full size: one GPU over all 10 M elements (64-bit indexing: 5.12e9 output
+    doubles) vs the eight shards run one after another; bit-identical union, equal checksum."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 85e9:
+        pytest.skip("needs ~80 GB of free HBM")
+    b = sf.fill_basis(NM, NQ)
+    x = sf.fill_random(TOTAL * NMT, SEED, 0)
+    full = sf.bwdtrans_hex((NQ,) * 3, b, b, b, x)
+    full_ss = sf.sumsq(full)
+    shard_ss = 0.0
+    for r in range(WORLD):
+        lo, hi = sf.shard.element_range(TOTAL, WORLD, r)
+        xs = sf.fill_random((hi - lo) * NMT, SEED, lo * NMT)
+        assert torch.equal(xs, x[lo * NMT:hi * NMT]), r
+        outs = sf.bwdtrans_hex((NQ,) * 3, b, b, b, xs)
+        assert torch.equal(outs, full[lo * NQT:hi * NQT]), r       # same kernel, same per-element arithmetic
+        shard_ss += sf.sumsq(outs)
+        del xs, outs
+    assert abs(shard_ss - full_ss) <= 1e-12 * full_ss
+    # and the single-GPU result is the oracle's at the shard seams and beyond 2^32 output doubles
+    for first in (0, 1_249_999, 8_388_607, 8_750_000 - 3, TOTAL - 129):
+        ref = _oracle_window(oracle, first, 129)
+        got = full[first * NQT:(first + 129) * NQT].cpu().numpy()
+        assert oracle.rel_err(got, ref) <= 1e-12, first
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_gpus(sf):
+    """`python bench.py --gpus 2` without a launcher on a 1-GPU box: fails loudly, prints no JSON line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has 2+ GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SF_BENCH_BACKEND")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert res.returncode != 0 and "1 GPU" in res.stderr and "{" not in res.stdout
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks_config4(sf):
+    """`python bench.py --gpus 2` with no launcher starts 2 ranks itself (gloo rehearsal: the ranks share this
+    box's GPU), defaults to the 10 M-element strong-scaling batch and reports the ranks actually reduced over."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SF_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["total_elements"] == TOTAL and rec["config"]["elements_per_gpu"] == TOTAL // 2
+    assert len(rec["roofline"]["per_gpu_frac"]) == 2 and "rehearsal" in rec
+    assert rec["single_gpu_same_batch_gdof_s"] > 50 and rec["speedup_vs_1gpu_same_batch"] > 0
+    # checksum of the sharded run == one rank over the whole batch
+    b = sf.fill_basis(NM, NQ)
+    x = sf.fill_random(TOTAL * NMT, SEED, 0)
+    full = math.sqrt(sf.sumsq(sf.bwdtrans_hex((NQ,) * 3, b, b, b, x)))
+    assert abs(rec["checksum_norm"] - full) <= 1e-12 * full

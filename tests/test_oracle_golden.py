@@ -133,6 +133,24 @@ def test_fast_build_matches_parity_build(oracle):
     assert oracle.rel_err(v, a) < 1e-14
 
 
+def test_blocked_form_is_the_same_sums(oracle):
+    """The register-blocked form timed as cpu_baseline: bit-identical to the 3-sweep form in the parity build
+    (same products, same ascending summation), to rounding in the FMA build, every order it exists for."""
+    for nq in range(2, 11):
+        nm, nelmt = nq - 1, 37
+        b = [oracle.fill_random(nm * nq, 31 + d) for d in range(3)]
+        x = oracle.fill_random(nelmt * nm ** 3, 9)
+        s = oracle.bwdtrans_hex((nq,) * 3, nelmt, *b, x, form="sweeps")
+        k = oracle.bwdtrans_hex((nq,) * 3, nelmt, *b, x, form="blocked")
+        assert oracle.has_blocked(nq) and np.array_equal(s, k), nq
+        f = oracle.bwdtrans_hex((nq,) * 3, nelmt, *b, x, form="blocked", fast=True)
+        assert oracle.rel_err(f, s) < 1e-14
+    assert not oracle.has_blocked(11)
+    with pytest.raises(ValueError):
+        oracle.bwdtrans_hex((3, 4, 3), 2, *[oracle.fill_basis(q - 1, q) for q in (3, 4, 3)],
+                            oracle.fill_random(2 * 2 * 3 * 2, 1), form="blocked")
+
+
 def test_random_generator_pinned(oracle):
     for seed, idx in [(0, 0), (0x5F3759DF, 12345), (7, (1 << 40) + 3)]:
         v = oracle.fill_random(1, seed, idx)[0]
