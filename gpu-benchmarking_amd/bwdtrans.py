@@ -15,10 +15,20 @@ VARIANTS = {"auto": 0, "wave": 1, "thread": 2, "block-lds": 3, "block-glb": 4, "
             "mfma": 6}
 
 
-def _stream(stream):
+def _stream(stream, device=None):
+    """hipStream_t of `stream`, or of the current stream of `device` (the tensor's device, not the thread's)."""
     if stream is None:
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream(device)
     return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _check_sizes(what, basis, nq, wsp, wsp_need):
+    """The C ABI takes raw pointers: a short basis or workspace would be read / written out of bounds."""
+    for d, (b, q) in enumerate(zip(basis, nq)):
+        if b.numel() != (q - 1) * q:
+            raise ValueError(f"{what}: basis{d} has {b.numel()} values, nm*nq = {(q - 1) * q}")
+    if wsp is not None and wsp.numel() < wsp_need:
+        raise ValueError(f"{what}: wsp has {wsp.numel()} values, the variant needs {wsp_need}")
 
 
 def _dev_f64(t, name, dtype=torch.float64):
@@ -60,12 +70,16 @@ def bwdtrans_hex(nq, basis0, basis1, basis2, inp, out=None, variant="auto", wsp=
         out = torch.empty(nelmt * nq0 * nq1 * nq2, dtype=inp.dtype, device=inp.device)
     elif out.numel() != nelmt * nq0 * nq1 * nq2:
         raise ValueError("out has the wrong size")
+    v = _variant(variant)
+    _check_sizes("bwdtrans_hex", (basis0, basis1, basis2), (nq0, nq1, nq2), wsp,
+                 {2: nelmt * ((nq1 - 1) * (nq2 - 1) + (nq2 - 1)),
+                  4: hex_wsp_doubles((nq0, nq1, nq2), nelmt)}.get(v, 0))
     if inp.dtype == torch.float32:      # T = float instantiation; AUTO strategy only
         with torch.cuda.device(inp.device):
             rc = capi.lib().sf_bwdtrans_hex_f32(
                 nq0, nq1, nq2, nelmt, _dev_f32(basis0, "basis0"), _dev_f32(basis1, "basis1"),
                 _dev_f32(basis2, "basis2"), _dev_f32(inp, "in"), _dev_f32(out, "out"),
-                _stream(stream))
+                _stream(stream, inp.device))
         capi.check(rc, "sf_bwdtrans_hex_f32")
         return out
     v = _variant(variant)
@@ -77,7 +91,7 @@ def bwdtrans_hex(nq, basis0, basis1, basis2, inp, out=None, variant="auto", wsp=
             v, nq0, nq1, nq2, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
             _dev_f64(basis2, "basis2"), _dev_f64(inp, "in"),
             _dev_f64(wsp, "wsp") if wsp is not None else None, _dev_f64(out, "out"),
-            _stream(stream))
+            _stream(stream, inp.device))
     capi.check(rc, "sf_bwdtrans_hex_f64")
     return out
 
@@ -95,11 +109,14 @@ def bwdtrans_quad(nq, basis0, basis1, inp, out=None, variant="auto", wsp=None, s
         out = torch.empty(nelmt * nq0 * nq1, dtype=inp.dtype, device=inp.device)
     elif out.numel() != nelmt * nq0 * nq1:
         raise ValueError("out has the wrong size")
+    v = _variant(variant)
+    _check_sizes("bwdtrans_quad", (basis0, basis1), (nq0, nq1), wsp,
+                 {2: nelmt * (nq1 - 1), 4: quad_wsp_doubles((nq0, nq1), nelmt)}.get(v, 0))
     if inp.dtype == torch.float32:
         with torch.cuda.device(inp.device):
             rc = capi.lib().sf_bwdtrans_quad_f32(
                 nq0, nq1, nelmt, _dev_f32(basis0, "basis0"), _dev_f32(basis1, "basis1"),
-                _dev_f32(inp, "in"), _dev_f32(out, "out"), _stream(stream))
+                _dev_f32(inp, "in"), _dev_f32(out, "out"), _stream(stream, inp.device))
         capi.check(rc, "sf_bwdtrans_quad_f32")
         return out
     v = _variant(variant)
@@ -110,7 +127,7 @@ def bwdtrans_quad(nq, basis0, basis1, inp, out=None, variant="auto", wsp=None, s
         rc = capi.lib().sf_bwdtrans_quad_f64_variant(
             v, nq0, nq1, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
             _dev_f64(inp, "in"), _dev_f64(wsp, "wsp") if wsp is not None else None,
-            _dev_f64(out, "out"), _stream(stream))
+            _dev_f64(out, "out"), _stream(stream, inp.device))
     capi.check(rc, "sf_bwdtrans_quad_f64")
     return out
 
@@ -121,7 +138,7 @@ def interleave64(src, nelmt, n, inverse=False, stream=None):
     dst = torch.zeros((nelmt if inverse else padded) * n, dtype=torch.float64, device=src.device)
     with torch.cuda.device(src.device):
         capi.check(capi.lib().sf_interleave64_f64(_dev_f64(src, "src"), _dev_f64(dst, "dst"), nelmt,
-                                                  n, 1 if inverse else 0, _stream(stream)),
+                                                  n, 1 if inverse else 0, _stream(stream, src.device)),
                    "sf_interleave64_f64")
     return dst
 
@@ -138,7 +155,7 @@ def bwdtrans_hex_interleaved(nq, basis0, basis1, basis2, in_il, nelmt, stream=No
         rc = capi.lib().sf_bwdtrans_hex_f64_interleaved(
             nq0, nq1, nq2, nelmt, _dev_f64(basis0, "basis0"), _dev_f64(basis1, "basis1"),
             _dev_f64(basis2, "basis2"), _dev_f64(in_il, "in_il"), _dev_f64(wsp, "wsp"),
-            _dev_f64(out, "out_il"), _stream(stream))
+            _dev_f64(out, "out_il"), _stream(stream, in_il.device))
     capi.check(rc, "sf_bwdtrans_hex_f64_interleaved")
     return out
 
@@ -149,10 +166,10 @@ def sumsq(x, stream=None):
     with torch.cuda.device(x.device):
         if x.dtype == torch.float32:
             rc = capi.lib().sf_sumsq_f32(_dev_f32(x, "x"), x.numel(), ctypes.byref(res),
-                                         _stream(stream))
+                                         _stream(stream, x.device))
         else:
             rc = capi.lib().sf_sumsq_f64(_dev_f64(x, "x"), x.numel(), ctypes.byref(res),
-                                         _stream(stream))
+                                         _stream(stream, x.device))
     capi.check(rc, "sf_sumsq")
     return res.value
 
@@ -172,27 +189,27 @@ def _sfx(dtype):
 
 def fill_sincos(nelmt, nm_tot, device="cuda", stream=None, dtype=torch.float64):
     """in[e][f] = sin((T)(f+1)) (benchmark05/benchmark05.cc:1206-1207), generated on the device."""
-    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_sincos_" + _sfx(dtype))
+    st, fn = _stream(stream, device), getattr(capi.lib(), "sf_fill_sincos_" + _sfx(dtype))
     return _filled(nelmt * nm_tot, device, lambda p: fn(p, nelmt, nm_tot, st), "sf_fill_sincos",
                    dtype)
 
 
 def fill_basis(nm, nq, device="cuda", stream=None, dtype=torch.float64):
     """basis[x] = cos((T)x) (benchmark05/benchmark05.cc:1220)."""
-    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_basis_" + _sfx(dtype))
+    st, fn = _stream(stream, device), getattr(capi.lib(), "sf_fill_basis_" + _sfx(dtype))
     return _filled(nm * nq, device, lambda p: fn(p, nm, nq, st), "sf_fill_basis", dtype)
 
 
 def fill_random(n, seed, first_idx=0, device="cuda", stream=None, dtype=torch.float64):
     """Seeded per-value-distinct U[-1,1) data; bit-identical to oracle.fill_random (rounded to
     float for dtype=float32)."""
-    st, fn = _stream(stream), getattr(capi.lib(), "sf_fill_random_" + _sfx(dtype))
+    st, fn = _stream(stream, device), getattr(capi.lib(), "sf_fill_random_" + _sfx(dtype))
     return _filled(n, device, lambda p: fn(p, n, seed, first_idx, st), "sf_fill_random", dtype)
 
 
 def fill_l2norm(n, device="cuda", stream=None):
     """x[i] = i%13 + (0.2 + 1e-5*(i%100191)) (benchmark01/benchmark01.cc:178)."""
-    st = _stream(stream)
+    st = _stream(stream, device)
     return _filled(n, device, lambda p: capi.lib().sf_fill_l2norm_f64(p, n, st),
                    "sf_fill_l2norm_f64")
 
@@ -200,7 +217,7 @@ def fill_l2norm(n, device="cuda", stream=None):
 def stream_copy(src, dst, stream=None):
     with torch.cuda.device(src.device):
         capi.check(capi.lib().sf_stream_copy_f64(_dev_f64(src, "src"), _dev_f64(dst, "dst"),
-                                                 src.numel(), _stream(stream)),
+                                                 src.numel(), _stream(stream, src.device)),
                    "sf_stream_copy_f64")
     return dst
 
@@ -211,7 +228,7 @@ def fill_vecadd(n, device="cuda", stream=None):
     y = torch.empty(n, dtype=torch.float64, device=device)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().sf_fill_vecadd_f64(_dev_f64(x, "x"), _dev_f64(y, "y"), n,
-                                                 _stream(stream)), "sf_fill_vecadd_f64")
+                                                 _stream(stream, x.device)), "sf_fill_vecadd_f64")
     return x, y
 
 
@@ -219,7 +236,7 @@ def vector_add(x, y, stream=None):
     """x += y in place (benchmark02's operation)."""
     with torch.cuda.device(x.device):
         capi.check(capi.lib().sf_vector_add_f64(_dev_f64(x, "x"), _dev_f64(y, "y"), x.numel(),
-                                                _stream(stream)), "sf_vector_add_f64")
+                                                _stream(stream, x.device)), "sf_vector_add_f64")
     return x
 
 
@@ -229,7 +246,7 @@ def fill_matvec(m, n, device="cuda", stream=None):
     x = torch.empty(n, dtype=torch.float64, device=device)
     with torch.cuda.device(a.device):
         capi.check(capi.lib().sf_fill_matvec_f64(_dev_f64(a, "A"), _dev_f64(x, "x"), m, n,
-                                                 _stream(stream)), "sf_fill_matvec_f64")
+                                                 _stream(stream, a.device)), "sf_fill_matvec_f64")
     return a, x
 
 
@@ -239,7 +256,7 @@ def matvec(m, n, a, x, y=None, stream=None):
         y = torch.empty(m, dtype=torch.float64, device=a.device)
     with torch.cuda.device(a.device):
         capi.check(capi.lib().sf_matvec_f64(m, n, _dev_f64(a, "A"), _dev_f64(x, "x"),
-                                            _dev_f64(y, "y"), _stream(stream)), "sf_matvec_f64")
+                                            _dev_f64(y, "y"), _stream(stream, a.device)), "sf_matvec_f64")
     return y
 
 

@@ -13,6 +13,7 @@
 #include "sf_dispatch.h"
 
 #include <mutex>
+#include <vector>
 
 namespace sf
 {
@@ -365,46 +366,109 @@ const DeviceInfo &device_info()
     return info[dev];
 }
 
+// Internal scratch: one buffer per (device, stream, kind), grown on demand.  Work enqueued on ONE stream is ordered, so
+// a buffer keyed by its stream is never used by two kernels at once; different streams (or devices) get different
+// buffers, which is what makes the entry points below safe to call concurrently on several streams / host threads.
+// g_scratch_mu covers the table AND is held by the callers across their whole enqueue sequence (kernel(s) + async
+// copy), so two host threads sharing a stream cannot interleave halves of two reductions.
+struct ScratchSlot
+{
+    int dev;
+    hipStream_t stream;
+    int kind;
+    void *ptr;
+    size_t bytes;
+    uint64_t tick;
+};
+static std::vector<ScratchSlot> g_scratch;
+static std::recursive_mutex g_scratch_mu;
+static uint64_t g_scratch_tick = 0;
+constexpr size_t kMaxScratchSlots = 128;
+
+std::recursive_mutex &scratch_mutex()
+{
+    return g_scratch_mu;
+}
+
+int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return SF_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
+    ScratchSlot *slot = nullptr;
+    for (auto &c : g_scratch)
+        if (c.dev == dev && c.stream == s && c.kind == kind)
+            slot = &c;
+    if (!slot)
+    {
+        if (g_scratch.size() >= kMaxScratchSlots)
+        {
+            // evict the least recently used slot of this device (hipFree waits for work that still uses it)
+            size_t victim = g_scratch.size();
+            for (size_t i = 0; i < g_scratch.size(); ++i)
+                if (g_scratch[i].dev == dev && (victim == g_scratch.size() || g_scratch[i].tick < g_scratch[victim].tick))
+                    victim = i;
+            if (victim == g_scratch.size())
+                return SF_ENOMEM;
+            (void)hipFree(g_scratch[victim].ptr);
+            g_scratch.erase(g_scratch.begin() + (long)victim);
+        }
+        g_scratch.push_back(ScratchSlot{dev, s, kind, nullptr, 0, 0});
+        slot = &g_scratch.back();
+    }
+    if (slot->bytes < bytes)
+    {
+        if (slot->ptr)
+            (void)hipFree(slot->ptr); // synchronises: nothing in flight still reads the old buffer
+        slot->ptr = nullptr;
+        slot->bytes = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return SF_ENOMEM;
+        }
+        slot->ptr   = p;
+        slot->bytes = bytes;
+    }
+    slot->tick = ++g_scratch_tick;
+    *out       = slot->ptr;
+    return SF_OK;
+}
+
 struct Workspace
 {
     double *part   = nullptr; // kRedMaxBlock partials + 1 result
     double *result = nullptr;
 };
 
-static Workspace g_ws[64];
-static std::mutex g_ws_mu;
-
-static int workspace(Workspace **ws)
+// reduction scratch of the calling stream (kind 0)
+static int workspace(hipStream_t s, Workspace *ws)
 {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64)
-        return SF_EINVAL;
-    std::lock_guard<std::mutex> lock(g_ws_mu);
-    Workspace &w = g_ws[dev];
-    if (!w.part)
-    {
-        hipError_t e = hipMalloc((void **)&w.part, sizeof(double) * (kRedMaxBlock + 8));
-        if (e != hipSuccess)
-        {
-            (void)hipGetLastError();
-            return SF_ENOMEM;
-        }
-        w.result = w.part + kRedMaxBlock;
-    }
-    *ws = &w;
+    void *p = nullptr;
+    int rc  = scratch_acquire(s, 0, sizeof(double) * (kRedMaxBlock + 8), &p);
+    if (rc != SF_OK)
+        return rc;
+    ws->part   = static_cast<double *>(p);
+    ws->result = ws->part + kRedMaxBlock;
     return SF_OK;
 }
 
 int release_workspaces()
 {
-    std::lock_guard<std::mutex> lock(g_ws_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && g_ws[dev].part)
+    for (size_t i = 0; i < g_scratch.size();)
     {
-        (void)hipFree(g_ws[dev].part);
-        g_ws[dev] = Workspace();
+        if (g_scratch[i].dev == dev)
+        {
+            (void)hipFree(g_scratch[i].ptr);
+            g_scratch.erase(g_scratch.begin() + (long)i);
+        }
+        else
+            ++i;
     }
     return SF_OK;
 }
@@ -424,8 +488,9 @@ static inline unsigned fill_grid(uint64_t n)
 
 int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s)
 {
-    Workspace *ws = nullptr;
-    int rc        = workspace(&ws);
+    std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
+    Workspace w, *ws = &w;
+    int rc = workspace(s, ws);
     if (rc != SF_OK)
         return rc;
     // fixed shape for a given n: deterministic result
@@ -452,14 +517,19 @@ int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s)
 
 int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s)
 {
-    Workspace *ws = nullptr;
-    int rc        = workspace(&ws);
-    if (rc != SF_OK)
-        return rc;
-    rc = sumsq_async(x, n, ws->result, s);
-    if (rc != SF_OK)
-        return rc;
-    hipError_t e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    hipError_t e;
+    {
+        // kernels + copy are enqueued as one unit; the wait happens outside the lock
+        std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
+        Workspace w, *ws = &w;
+        int rc = workspace(s, ws);
+        if (rc != SF_OK)
+            return rc;
+        rc = sumsq_async(x, n, ws->result, s);
+        if (rc != SF_OK)
+            return rc;
+        e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    }
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
     return e == hipSuccess ? SF_OK : (int)e;
@@ -467,21 +537,25 @@ int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s
 
 int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s)
 {
-    Workspace *ws = nullptr;
-    int rc        = workspace(&ws);
-    if (rc != SF_OK)
-        return rc;
-    uint64_t blocks = (n + (uint64_t)kRedThreads * 16 - 1) / ((uint64_t)kRedThreads * 16);
-    if (blocks < 1)
-        blocks = 1;
-    if (blocks > kRedMaxBlock)
-        blocks = kRedMaxBlock;
-    sumsq_partial_f32_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
-    sumsq_final_kernel<<<1, kRedThreads, 0, s>>>(ws->part, (int)blocks, ws->result);
-    rc = launch_rc();
-    if (rc != SF_OK)
-        return rc;
-    hipError_t e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    hipError_t e;
+    {
+        std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
+        Workspace w, *ws = &w;
+        int rc = workspace(s, ws);
+        if (rc != SF_OK)
+            return rc;
+        uint64_t blocks = (n + (uint64_t)kRedThreads * 16 - 1) / ((uint64_t)kRedThreads * 16);
+        if (blocks < 1)
+            blocks = 1;
+        if (blocks > kRedMaxBlock)
+            blocks = kRedMaxBlock;
+        sumsq_partial_f32_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
+        sumsq_final_kernel<<<1, kRedThreads, 0, s>>>(ws->part, (int)blocks, ws->result);
+        rc = launch_rc();
+        if (rc != SF_OK)
+            return rc;
+        e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+    }
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
     return e == hipSuccess ? SF_OK : (int)e;

@@ -18,33 +18,43 @@ namespace sf
 {
 
 // ------------------------------------------------------------------------------------------------
-template <bool GLOBAL_WSP, typename T>
+// BASIS_LDS = false: the bases are read from global memory (cached) -- only for extents whose bases alone exceed the
+// LDS.  wsp_by_block: the global workspace holds one (w1, w2) pair per WORKGROUP (the library's own bounded scratch)
+// instead of one per element (the reference's caller-owned layout, benchmark05.cc:1243-1244).
+// LDS mode: w2 is written where the element's input image was -- the image is dead once sweep 1 has run -- so the
+// LDS need is bases + max(nm^3, nq0 nq1 nm2) + nq0 nm1 nm2 scalars (the reference keeps all three, :299-305).
+template <bool GLOBAL_WSP, bool BASIS_LDS, typename T>
 __global__ __launch_bounds__(256) void hex_block_kernel(unsigned nq0, unsigned nq1, unsigned nq2,
-                                                        HexArgsT<T> a)
+                                                        HexArgsT<T> a, int wsp_by_block)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1, nm2 = nq2 - 1;
     const unsigned nmt = nm0 * nm1 * nm2, nqt = nq0 * nq1 * nq2;
     const unsigned n1 = nq0 * nm1 * nm2, n2 = nq0 * nq1 * nm2;
-    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0, *sb2 = sb1 + nm1 * nq1;
-    T *sin_ = sb2 + nm2 * nq2;
-    T *sw1  = sin_ + nmt;
-    T *sw2  = sw1 + n1;
+    const unsigned nb = BASIS_LDS ? nm0 * nq0 + nm1 * nq1 + nm2 * nq2 : 0;
+    const T *sb0 = a.b0, *sb1 = a.b1, *sb2 = a.b2;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-
-    for (unsigned x = tid; x < nm0 * nq0; x += nt)
-        sb0[x] = a.b0[x];
-    for (unsigned x = tid; x < nm1 * nq1; x += nt)
-        sb1[x] = a.b1[x];
-    for (unsigned x = tid; x < nm2 * nq2; x += nt)
-        sb2[x] = a.b2[x];
+    if (BASIS_LDS)
+    {
+        T *l0 = lds, *l1 = l0 + nm0 * nq0, *l2 = l1 + nm1 * nq1;
+        for (unsigned x = tid; x < nm0 * nq0; x += nt)
+            l0[x] = a.b0[x];
+        for (unsigned x = tid; x < nm1 * nq1; x += nt)
+            l1[x] = a.b1[x];
+        for (unsigned x = tid; x < nm2 * nq2; x += nt)
+            l2[x] = a.b2[x];
+        sb0 = l0, sb1 = l1, sb2 = l2;
+    }
+    T *sin_ = lds + nb;                       // input image, later w2
+    T *sw2  = sin_;
+    T *sw1  = sin_ + (nmt > n2 ? nmt : n2);
 
     for (uint64_t e = blockIdx.x; e < a.nelmt; e += gridDim.x)
     {
         const T *ine = a.in + e * nmt;
         T *oute      = a.out + e * nqt;
-        T *w1        = GLOBAL_WSP ? a.wsp + e * (uint64_t)(n1 + n2) : sw1;
+        T *w1        = GLOBAL_WSP ? a.wsp + (wsp_by_block ? (uint64_t)blockIdx.x : e) * (uint64_t)(n1 + n2) : sw1;
         T *w2        = GLOBAL_WSP ? w1 + n1 : sw2;
         const T *src = ine;
         if (!GLOBAL_WSP)
@@ -141,26 +151,33 @@ __global__ __launch_bounds__(256) void hex_thread_kernel(unsigned nq0, unsigned 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool GLOBAL_WSP, typename T>
-__global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a)
+template <bool GLOBAL_WSP, bool BASIS_LDS, typename T>
+__global__ __launch_bounds__(256) void quad_block_kernel(unsigned nq0, unsigned nq1, QuadArgsT<T> a,
+                                                         int wsp_by_block)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *lds = reinterpret_cast<T *>(lds_raw);
     const unsigned nm0 = nq0 - 1, nm1 = nq1 - 1;
     const unsigned nmt = nm0 * nm1, nqt = nq0 * nq1, n1 = nq0 * nm1;
-    T *sb0 = lds, *sb1 = sb0 + nm0 * nq0;
-    T *sin_ = sb1 + nm1 * nq1;
-    T *sw   = sin_ + nmt;
+    const unsigned nb = BASIS_LDS ? nm0 * nq0 + nm1 * nq1 : 0;
+    const T *sb0 = a.b0, *sb1 = a.b1;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-    for (unsigned x = tid; x < nm0 * nq0; x += nt)
-        sb0[x] = a.b0[x];
-    for (unsigned x = tid; x < nm1 * nq1; x += nt)
-        sb1[x] = a.b1[x];
+    if (BASIS_LDS)
+    {
+        T *l0 = lds, *l1 = l0 + nm0 * nq0;
+        for (unsigned x = tid; x < nm0 * nq0; x += nt)
+            l0[x] = a.b0[x];
+        for (unsigned x = tid; x < nm1 * nq1; x += nt)
+            l1[x] = a.b1[x];
+        sb0 = l0, sb1 = l1;
+    }
+    T *sin_ = lds + nb;
+    T *sw   = sin_ + nmt;
     for (uint64_t e = blockIdx.x; e < a.nelmt; e += gridDim.x)
     {
         const T *ine = a.in + e * nmt;
         T *oute      = a.out + e * nqt;
-        T *w         = GLOBAL_WSP ? a.wsp + e * (uint64_t)n1 : sw;
+        T *w         = GLOBAL_WSP ? a.wsp + (wsp_by_block ? (uint64_t)blockIdx.x : e) * (uint64_t)n1 : sw;
         const T *src = ine;
         if (!GLOBAL_WSP)
         {
@@ -371,30 +388,46 @@ int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, 
             nq0, nq1, nq2, a);
         return launch_rc();
     }
-    const bool glb = (variant == SF_VARIANT_BLOCK_GLB);
-    if (glb && !a.wsp)
-        return SF_EINVAL;
-    size_t lds = sizeof(T) * nbas;
-    if (!glb)
-        lds += sizeof(T) * (nm0 * nm1 * nm2 + nq0 * nm1 * nm2 + nq0 * nq1 * nm2);
-    if (lds > kMaxDynLds)
+    // LDS-resident sweeps: bases + input image / w2 (aliased) + w1
+    const size_t nmt = nm0 * nm1 * nm2, n1 = nq0 * nm1 * nm2, n2 = (size_t)nq0 * nq1 * nm2;
+    const size_t lds_full = sizeof(T) * (nbas + (nmt > n2 ? nmt : n2) + n1);
+    const bool bases_fit  = sizeof(T) * nbas <= kMaxDynLds;
+    bool glb = (variant == SF_VARIANT_BLOCK_GLB), by_block = false;
+    if (variant == SF_VARIANT_BLOCK_LDS && lds_full > kMaxDynLds)
         return SF_ENOTBUILT;
-    const unsigned nqt   = nq0 * nq1 * nq2;
-    const unsigned thr   = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
-    const uint64_t cap   = (uint64_t)cu * 32;
-    const unsigned grid  = hinted_grid(a.nelmt, cap);
-    if (glb)
+    if (variant == SF_VARIANT_GENERIC && lds_full > kMaxDynLds)
+        glb = by_block = true; // the element's images exceed the 160 KiB of LDS: intermediates in the library's scratch
+    if (glb && !by_block && !a.wsp)
+        return SF_EINVAL;
+    const unsigned nqt = nq0 * nq1 * nq2;
+    const unsigned thr = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
+    const uint64_t cap = (uint64_t)cu * 32;
+    unsigned grid      = hinted_grid(a.nelmt, cap);
+    HexArgsT<T> args   = a;
+    // scratch and launch are one unit (see scratch_acquire)
+    std::unique_lock<std::recursive_mutex> lock(scratch_mutex(), std::defer_lock);
+    if (by_block)
     {
-        (void)hipFuncSetAttribute((const void *)hex_block_kernel<true, T>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hex_block_kernel<true, T><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
+        lock.lock();
+        grid = (unsigned)(a.nelmt < (uint64_t)cu * 8 ? a.nelmt : (uint64_t)cu * 8);
+        void *p = nullptr;
+        int rc  = scratch_acquire(s, 1, sizeof(T) * (n1 + n2) * grid, &p);
+        if (rc != SF_OK)
+            return rc;
+        args.wsp = static_cast<T *>(p);
     }
+    const size_t lds = glb ? (bases_fit ? sizeof(T) * nbas : 0) : lds_full;
+    auto go          = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kern<<<grid, thr, lds, s>>>(nq0, nq1, nq2, args, by_block ? 1 : 0);
+    };
+    if (!glb)
+        go(hex_block_kernel<false, true, T>);
+    else if (bases_fit)
+        go(hex_block_kernel<true, true, T>);
     else
-    {
-        (void)hipFuncSetAttribute((const void *)hex_block_kernel<false, T>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hex_block_kernel<false, T><<<grid, thr, lds, s>>>(nq0, nq1, nq2, a);
-    }
+        go(hex_block_kernel<true, false, T>);
     return launch_rc();
 }
 
@@ -417,30 +450,44 @@ int launch_quad_generic_t(int variant, unsigned nq0, unsigned nq1, const QuadArg
             nq0, nq1, a);
         return launch_rc();
     }
-    const bool glb = (variant == SF_VARIANT_BLOCK_GLB);
-    if (glb && !a.wsp)
-        return SF_EINVAL;
-    size_t lds = sizeof(T) * nbas;
-    if (!glb)
-        lds += sizeof(T) * (nm0 * nm1 + nq0 * nm1);
-    if (lds > kMaxDynLds)
+    const size_t nmt = nm0 * nm1, n1 = nq0 * nm1;
+    const size_t lds_full = sizeof(T) * (nbas + nmt + n1);
+    const bool bases_fit  = sizeof(T) * nbas <= kMaxDynLds;
+    bool glb = (variant == SF_VARIANT_BLOCK_GLB), by_block = false;
+    if (variant == SF_VARIANT_BLOCK_LDS && lds_full > kMaxDynLds)
         return SF_ENOTBUILT;
-    const unsigned nqt  = nq0 * nq1;
-    const unsigned thr  = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
-    const uint64_t cap  = (uint64_t)cu * 32;
-    const unsigned grid = hinted_grid(a.nelmt, cap);
-    if (glb)
+    if (variant == SF_VARIANT_GENERIC && lds_full > kMaxDynLds)
+        glb = by_block = true;
+    if (glb && !by_block && !a.wsp)
+        return SF_EINVAL;
+    const unsigned nqt = nq0 * nq1;
+    const unsigned thr = hinted_block(nqt <= 64 ? 64 : (nqt <= 128 ? 128 : 256), nqt);
+    const uint64_t cap = (uint64_t)cu * 32;
+    unsigned grid      = hinted_grid(a.nelmt, cap);
+    QuadArgsT<T> args  = a;
+    std::unique_lock<std::recursive_mutex> lock(scratch_mutex(), std::defer_lock);
+    if (by_block)
     {
-        (void)hipFuncSetAttribute((const void *)quad_block_kernel<true, T>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        quad_block_kernel<true, T><<<grid, thr, lds, s>>>(nq0, nq1, a);
+        lock.lock();
+        grid = (unsigned)(a.nelmt < (uint64_t)cu * 8 ? a.nelmt : (uint64_t)cu * 8);
+        void *p = nullptr;
+        int rc  = scratch_acquire(s, 1, sizeof(T) * n1 * grid, &p);
+        if (rc != SF_OK)
+            return rc;
+        args.wsp = static_cast<T *>(p);
     }
+    const size_t lds = glb ? (bases_fit ? sizeof(T) * nbas : 0) : lds_full;
+    auto go          = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kern<<<grid, thr, lds, s>>>(nq0, nq1, args, by_block ? 1 : 0);
+    };
+    if (!glb)
+        go(quad_block_kernel<false, true, T>);
+    else if (bases_fit)
+        go(quad_block_kernel<true, true, T>);
     else
-    {
-        (void)hipFuncSetAttribute((const void *)quad_block_kernel<false, T>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        quad_block_kernel<false, T><<<grid, thr, lds, s>>>(nq0, nq1, a);
-    }
+        go(quad_block_kernel<true, false, T>);
     return launch_rc();
 }
 

@@ -150,6 +150,11 @@ int launch_hex_wave_f32_nq(unsigned nq, const HexArgsT<float> &a, hipStream_t s)
     case 9: return go_f32<9>(a, s);
     case 10: return go_f32<10>(a, s);
     case 11: return go_f32<11>(a, s);
+    case 12: return go_f32<12>(a, s);
+    case 13: return go_f32<13>(a, s);
+    case 14: return go_f32<14>(a, s);
+    case 15: return go_f32<15>(a, s);
+    case 16: return go_f32<16>(a, s);
     default: return SF_ENOTBUILT;
     }
 }

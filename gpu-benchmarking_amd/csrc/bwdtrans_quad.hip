@@ -68,7 +68,7 @@ template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
 }
 
-// fp32 (T = float): the vector-ALU kernel for every built order (no fp32 matrix-core variant)
+// fp32 (T = float): the vector-ALU kernel for every order 2..32 (no fp32 matrix-core variant)
 int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s)
 {
     switch (nq)
@@ -77,6 +77,7 @@ int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t 
         SF_CASE(2) SF_CASE(3) SF_CASE(4) SF_CASE(5) SF_CASE(6) SF_CASE(7) SF_CASE(8) SF_CASE(9)
         SF_CASE(10) SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16)
         SF_CASE(17) SF_CASE(18) SF_CASE(19) SF_CASE(20) SF_CASE(21) SF_CASE(22) SF_CASE(23) SF_CASE(24)
+        SF_CASE(25) SF_CASE(26) SF_CASE(27) SF_CASE(28) SF_CASE(29) SF_CASE(30) SF_CASE(31)
         SF_CASE(32)
 #undef SF_CASE
     default: return SF_ENOTBUILT;

@@ -72,7 +72,7 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
-        return launch_hex_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+        return launch_hex_generic(SF_VARIANT_GENERIC, nq0, nq1, nq2, a, s);
     }
     case SF_VARIANT_WAVE:
         if (!iso)
@@ -87,7 +87,7 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
             return SF_EALIGN;
         return launch_hex_mfma_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
-        return launch_hex_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+        return launch_hex_generic(SF_VARIANT_GENERIC, nq0, nq1, nq2, a, s);
     case SF_VARIANT_THREAD:
     case SF_VARIANT_BLOCK_LDS:
     case SF_VARIANT_BLOCK_GLB:
@@ -136,7 +136,7 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
-        return launch_quad_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+        return launch_quad_generic(SF_VARIANT_GENERIC, nq0, nq1, a, s);
     }
     case SF_VARIANT_WAVE:
         if (!iso)
@@ -151,7 +151,7 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
             return SF_EALIGN;
         return launch_quad_mfma_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
-        return launch_quad_generic(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+        return launch_quad_generic(SF_VARIANT_GENERIC, nq0, nq1, a, s);
     case SF_VARIANT_THREAD:
     case SF_VARIANT_BLOCK_LDS:
     case SF_VARIANT_BLOCK_GLB:
@@ -214,7 +214,7 @@ int sf_bwdtrans_hex_f32(unsigned nq0, unsigned nq1, unsigned nq2, size_t nelmt, 
         if (rc != SF_ENOTBUILT)
             return rc;
     }
-    return launch_hex_generic_f32(SF_VARIANT_BLOCK_LDS, nq0, nq1, nq2, a, s);
+    return launch_hex_generic_f32(SF_VARIANT_GENERIC, nq0, nq1, nq2, a, s);
 }
 
 int sf_bwdtrans_quad_f32(unsigned nq0, unsigned nq1, size_t nelmt, const float *basis0,
@@ -236,7 +236,7 @@ int sf_bwdtrans_quad_f32(unsigned nq0, unsigned nq1, size_t nelmt, const float *
         if (rc != SF_ENOTBUILT)
             return rc;
     }
-    return launch_quad_generic_f32(SF_VARIANT_BLOCK_LDS, nq0, nq1, a, s);
+    return launch_quad_generic_f32(SF_VARIANT_GENERIC, nq0, nq1, a, s);
 }
 
 int sf_sumsq_f32(const float *x, size_t n, double *result_host, void *stream)

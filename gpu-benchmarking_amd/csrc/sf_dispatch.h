@@ -5,6 +5,8 @@
 
 #include "sf_common.h"
 
+#include <mutex>
+
 namespace sf
 {
 int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
@@ -27,6 +29,10 @@ int fill_vecadd(double *x, double *y, size_t n, hipStream_t s);
 int matvec(unsigned M, unsigned N, const double *A, const double *x, double *y, hipStream_t s);
 int fill_matvec(double *A, double *x, unsigned M, unsigned N, hipStream_t s);
 int release_workspaces();
+// internal scratch buffer of (current device, stream, kind), at least `bytes` long; kinds: 0 reductions, 1 BwdTrans
+// intermediates.  Hold scratch_mutex() from the acquire to the end of the enqueue sequence that uses the buffer.
+int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out);
+std::recursive_mutex &scratch_mutex();
 int set_launch_hint(unsigned threads, unsigned elblocks);
 int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
 int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,

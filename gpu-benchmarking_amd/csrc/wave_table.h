@@ -108,16 +108,44 @@ template <int NQ> struct QuadCfgF32
     static constexpr int MW = QuadCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = quad_f32_mf(NQ);
 };
 
-// fp32, 2D nq = 12, 15, 16: the doubled chunks (16-20 elements) leave 8 waves per CU; four-element chunks measure
-// 726 / 705 / 723 GDOF/s against 670 / 528 / 640 (profiles/r01/tune_f32_chunk_size_2d.log)
-#define SF_QUAD_F32(NQ_, MF_)                                                                      \
+// fp32, 2D nq = 12 .. 16, pinned row by row (not derived from the fp64 rows, which are re-tuned independently): the doubled
+// chunks (16-20 elements) leave 8 waves per CU; four-element chunks measure 721-728 / 727-738 / 727-733 / 770 GDOF/s at
+// nq = 12 / 14 / 15 / 16 against 694-701 / 699-712 / 553-558 / 655-659; nq = 13 keeps 16 elements at two waves per SIMD
+// (709-716 / 701 mean against 680 / 660) -- profiles/r02/tune_f32_chunk_size_2d.log
+#define SF_QUAD_F32(NQ_, EC_, MW_, MF_)                                                            \
     template <> struct QuadCfgF32<NQ_>                                                             \
     {                                                                                              \
-        static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM_COLS16, MW = 4, KM = 1, OUT = OUT_LDS, MF = MF_; \
+        static constexpr int EC = EC_, WPB = 4, BM = BASIS_SMEM_COLS16, MW = MW_, KM = 1, OUT = OUT_LDS, MF = MF_; \
     }
-SF_QUAD_F32(12, XG64);
-SF_QUAD_F32(15, XG64 | 12);
-SF_QUAD_F32(16, XG64);
+SF_QUAD_F32(12, 4, 4, XG64);
+SF_QUAD_F32(13, 16, 2, XG64 | 12);
+SF_QUAD_F32(14, 4, 4, XG64);
+SF_QUAD_F32(15, 4, 4, XG64 | 12);
+SF_QUAD_F32(16, 4, 4, XG64);
+SF_QUAD_F32(20, 8, 4, XG64); // 563 / 520 (six elements: 2 x the fp64 row; four: 490 / 478)
+// nq 25..31: fp64 runs these orders on the matrix cores (no fp32 MFMA kernel here); in fp32 the vector-ALU kernel's
+// registers fit (two elements: one pencil pass, 61 VGPRs of operands), so the T = float rows extend the wave table
+SF_QUAD_F32(25, 2, 4, XG64 | 8);
+SF_QUAD_F32(26, 2, 4, XG64);
+SF_QUAD_F32(27, 2, 4, XG64 | 8);
+SF_QUAD_F32(28, 2, 4, XG64);
+SF_QUAD_F32(29, 2, 4, XG64 | 8);
+SF_QUAD_F32(30, 2, 4, XG64);
+SF_QUAD_F32(31, 2, 4, XG64 | 8);
 #undef SF_QUAD_F32
+
+// fp32, 3D nq = 12 .. 16: fp64 uses the matrix-core kernel there (the fp64 wave kernel would need > 256 VGPRs); with
+// 4-byte scalars one element per wave fits (4 pencil passes: 124 VGPRs of operands at nq = 16, 16 KB of LDS per wave)
+#define SF_HEX_F32(NQ_, WPB_, MW_, MF_)                                                            \
+    template <> struct HexCfgF32<NQ_>                                                              \
+    {                                                                                              \
+        static constexpr int EC = 1, WPB = WPB_, BM = BASIS_SMEM, MW = MW_, KM = 1, OUT = OUT_LDS, MF = MF_; \
+    }
+SF_HEX_F32(12, 4, 2, XG64);
+SF_HEX_F32(13, 4, 2, XG64 | 8);
+SF_HEX_F32(14, 4, 2, XG64);
+SF_HEX_F32(15, 2, 2, XG64 | 8);
+SF_HEX_F32(16, 2, 2, XG64);
+#undef SF_HEX_F32
 
 } // namespace sf

@@ -76,15 +76,16 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
         if ((!g_opt.baselines || kF32) && v != 3)
             continue;
         HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
+        bool col_missing = false;
         auto launch = [&]()
         {
             if constexpr (kF32)
-                SF_CHECK(sf_bwdtrans_quad_f32(nq0, nq1, nelmt, d_basis0.get(), d_basis1.get(),
+                SF_COLUMN(sf_bwdtrans_quad_f32(nq0, nq1, nelmt, d_basis0.get(), d_basis1.get(),
                                               d_in.get(), d_out.get(), nullptr));
             else
             {
                 if (variants[v] >= 0)
-                    SF_CHECK(sf_bwdtrans_quad_f64_variant(variants[v], nq0, nq1, nelmt,
+                    SF_COLUMN(sf_bwdtrans_quad_f64_variant(variants[v], nq0, nq1, nelmt,
                                                           d_basis0.get(), d_basis1.get(), d_in.get(),
                                                           d_wsp.get(), d_out.get(), nullptr));
 #ifdef SF_WITH_ROCBLAS
@@ -103,6 +104,8 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
 #endif
         launch();
         HIP_CHECK(hipDeviceSynchronize());
+        if (col_missing) // not built for these extents: the column prints 0
+            continue;
         times[v] = time_min(launch, v >= 3 ? 1e30 : kSlowBudgetS);
         if constexpr (kF32)
             SF_CHECK(sf_sumsq_f32(d_out.get(), nelmt * nqTot, &results[v], nullptr));

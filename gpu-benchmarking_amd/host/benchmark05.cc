@@ -97,20 +97,21 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
         if ((!g_opt.baselines || kF32) && v != 3)
             continue;
         HIP_CHECK(hipMemsetAsync(d_out.get(), 0, nelmt * nqTot * sizeof(T), nullptr));
+        bool col_missing = false;
         auto launch = [&]()
         {
             if constexpr (kF32)
-                SF_CHECK(sf_bwdtrans_hex_f32(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(),
+                SF_COLUMN(sf_bwdtrans_hex_f32(nq0, nq1, nq2, nelmt, d_basis0.get(), d_basis1.get(),
                                              d_basis2.get(), d_in.get(), d_out.get(), nullptr));
             else
             {
                 if (variants[v] == -2)
-                    SF_CHECK(sf_bwdtrans_hex_f64_interleaved(nq0, nq1, nq2, nelmt, d_basis0.get(),
+                    SF_COLUMN(sf_bwdtrans_hex_f64_interleaved(nq0, nq1, nq2, nelmt, d_basis0.get(),
                                                              d_basis1.get(), d_basis2.get(),
                                                              d_in_il.get(), d_wsp_il.get(),
                                                              d_out_il.get(), nullptr));
                 else if (variants[v] >= 0)
-                    SF_CHECK(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
+                    SF_COLUMN(sf_bwdtrans_hex_f64_variant(variants[v], nq0, nq1, nq2, nelmt,
                                                          d_basis0.get(), d_basis1.get(),
                                                          d_basis2.get(), d_in.get(), d_wsp.get(),
                                                          d_out.get(), nullptr));
@@ -130,6 +131,8 @@ void run_test(const unsigned int size, const unsigned int _nq0, const unsigned i
 #endif
         launch(); // first touch outside the timed loop
         HIP_CHECK(hipDeviceSynchronize());
+        if (col_missing) // not built for these extents: the column prints 0
+            continue;
         times[v] = time_min(launch, (v == 3 || v == 4) ? 1e30 : kSlowBudgetS);
         if constexpr (kF32)
             SF_CHECK(sf_sumsq_f32(d_out.get(), nelmt * nqTot, &results[v], nullptr));

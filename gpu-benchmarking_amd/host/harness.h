@@ -50,6 +50,26 @@
         }                                                                                          \
     } while (0)
 
+// Inside a column's launch lambda: a variant that is not built for these extents (SF_ENOTBUILT, e.g. the LDS-resident
+// baseline at an order whose images exceed the LDS) marks the column as missing -- it prints 0 -- instead of ending
+// the run; every other error still exits.  Needs a `bool col_missing` in scope.
+#define SF_COLUMN(expr)                                                                            \
+    do                                                                                             \
+    {                                                                                              \
+        int rc_ = (expr);                                                                          \
+        if (rc_ == SF_ENOTBUILT)                                                                   \
+        {                                                                                          \
+            col_missing = true;                                                                    \
+            return;                                                                                \
+        }                                                                                          \
+        if (rc_ != SF_OK)                                                                          \
+        {                                                                                          \
+            std::cerr << "sumfact error " << rc_ << " (" << sf_error_string(rc_) << ") at "        \
+                      << __FILE__ << ":" << __LINE__ << " (" #expr ")" << std::endl;               \
+            std::exit(3);                                                                          \
+        }                                                                                          \
+    } while (0)
+
 namespace harness
 {
 

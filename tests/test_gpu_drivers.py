@@ -151,3 +151,32 @@ def test_anisotropic_cli(pkg, oracle):
     norm = math.sqrt(oracle.sumsq(ref))
     for v in log.norms[0]:
         assert abs(v - norm) <= 1e-9 * norm           # all six columns incl. rocBLAS, interleaved
+
+
+def test_benchmark05_any_order_cli(pkg, oracle):
+    """`./benchmark05 20 20 20` and `22 22 22` (the reference takes any atoi order, benchmark05.cc:1425-1429):
+    every built column reproduces the oracle's norm; at nq = 22 the LDS-resident baseline no longer fits the 160 KiB
+    of LDS and its column prints 0 instead of ending the run."""
+    import math
+    for nq, nelmt in ((20, 1000), (22, 300)):
+        out = _run([os.path.join(BIN, "benchmark05"), str(nq), str(nq), str(nq), "--nelmt", str(nelmt)])
+        log = pkg.logfmt.parse_log(out)
+        b = oracle.fill_basis(nq - 1, nq)
+        ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, b, b, b, oracle.fill_sincos(nelmt, (nq - 1) ** 3))
+        norm = math.sqrt(oracle.sumsq(ref))
+        for col, (v, rate) in enumerate(zip(log.norms[0], log.values[0])):
+            if nq == 22 and col == 2:
+                assert v == 0.0 and rate == 0.0
+            else:
+                assert abs(v - norm) <= 1e-9 * norm and rate > 0.0, (nq, col, v, norm)
+
+
+def test_benchmark05_fp32_above_the_fp64_tables(pkg, oracle):
+    """`--precision f32` at an order the fp64 wave table does not hold (nq = 14: fp32 wave kernel)."""
+    import math
+    out = _run([os.path.join(BIN, "benchmark05"), "14", "14", "14", "--nelmt", "4096", "--precision", "f32"])
+    log = pkg.logfmt.parse_log(out)
+    b = oracle.fill_basis(13, 14)
+    ref = oracle.bwdtrans_hex((14,) * 3, 4096, b, b, b, oracle.fill_sincos(4096, 13 ** 3))
+    norm = math.sqrt(oracle.sumsq(ref))
+    assert abs(log.norms[0][3] - norm) <= 5e-5 * norm and log.values[0][3] > 50.0

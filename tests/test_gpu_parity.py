@@ -368,6 +368,76 @@ def test_fp32_parity(sf, oracle, golden, torch_mod):
     assert abs(norm - want) <= 2e-5 * want
 
 
+def test_runtime_arbitrary_orders(sf, oracle, torch_mod):
+    """The reference accepts any atoi order (benchmark05/benchmark05.cc:1425-1429) and its global-workspace kernels
+    run it (:203-289).  AUTO above every table: LDS-resident generic kernel while one element's images fit the
+    160 KiB of LDS (3D nq <= 21), then the library's own bounded scratch (one w1/w2 pair per workgroup); explicit
+    BLOCK_LDS reports SF_ENOTBUILT instead of falling back."""
+    for nq, nelmt in (((17, 17, 17), 37), ((20, 20, 20), 1000), ((21, 21, 21), 9), ((22, 22, 22), 7),
+                      ((26, 26, 26), 3), ((24, 20, 18), 5), ((33, 2, 30), 11), ((40, 3, 3), 13)):
+        assert _hex_case(sf, oracle, nq, nelmt, "auto") <= TOL, nq
+        assert _hex_case(sf, oracle, nq, nelmt, "generic") <= TOL, nq
+    # more elements than scratch slots (grid-stride reuse of a workgroup's w1/w2) and a second stream
+    assert _hex_case(sf, oracle, (22, 22, 22), 2100, "auto") <= TOL
+    side = torch_mod.cuda.Stream()
+    with torch_mod.cuda.stream(side):
+        assert _hex_case(sf, oracle, (23, 23, 23), 5, "auto") <= TOL
+    side.synchronize()
+    with pytest.raises(sf.capi.SumfactError) as ei:
+        _hex_case(sf, oracle, (22, 22, 22), 3, "block-lds")
+    assert ei.value.rc == sf.capi.SF_ENOTBUILT
+    assert _hex_case(sf, oracle, (22, 22, 22), 3, "block-glb") <= TOL      # caller-owned workspace, reference layout
+    for nq, nelmt in (((33, 33), 129), ((40, 40), 77), ((72, 72), 9), ((100, 100), 5), ((100, 3), 40)):
+        assert _quad_case(sf, oracle, nq, nelmt, "auto") <= TOL, nq
+
+
+def test_fp32_beyond_the_fp64_wave_tables(sf, oracle, torch_mod):
+    """T = float (a template parameter of every reference kernel, benchmark05/benchmark05.cc:291): hex nq 12..16 and
+    quad nq 25..31 run the fp32 wave kernel (fp64 uses the matrix cores there); above that the generic kernels."""
+    f32 = torch_mod.float32
+    for nq in list(range(12, 18)) + [20, 22]:
+        nm = nq - 1
+        for nelmt in (1, 2, 7, 65, 130) if nq <= 16 else (5,):
+            bs = [sf.fill_random(nm * nq, 31 + d, dtype=f32) for d in range(3)]
+            x = sf.fill_random(nelmt * nm ** 3, nelmt, dtype=f32)
+            out = sf.bwdtrans_hex((nq,) * 3, *bs, x)
+            ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *[_np(b).astype(np.float64) for b in bs],
+                                      _np(x).astype(np.float64))
+            assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nq, nelmt)
+    for nq in list(range(25, 32)) + [33, 48]:
+        nm = nq - 1
+        for nelmt in (1, 2, 3, 64, 999):
+            bs = [sf.fill_random(nm * nq, 41 + d, dtype=f32) for d in range(2)]
+            x = sf.fill_random(nelmt * nm * nm, nelmt, dtype=f32)
+            out = sf.bwdtrans_quad((nq, nq), *bs, x)
+            ref = oracle.bwdtrans_quad((nq, nq), nelmt, *[_np(b).astype(np.float64) for b in bs],
+                                       _np(x).astype(np.float64))
+            assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nq, nelmt)
+
+
+def test_sumsq_concurrent_streams(sf, oracle, torch_mod):
+    """Reductions in flight on several streams / host threads of one device use per-stream scratch: every result
+    equals the single-stream result bit for bit."""
+    import threading
+    xs = [sf.fill_random(1_000_003 + 4099 * i, 50 + i) for i in range(6)]
+    want = [sf.sumsq(x) for x in xs]
+    got = [[None] * 8 for _ in xs]
+
+    def work(i):
+        st = torch_mod.cuda.Stream()
+        for rep in range(8):
+            got[i][rep] = sf.sumsq(xs[i], stream=st)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i, w in enumerate(want):
+        assert all(g == w for g in got[i]), i
+        assert abs(w - oracle.sumsq(_np(xs[i]))) <= 1e-12 * w
+
+
 def test_launch_hints(sf, oracle):
     """threads / elblocks (the reference CLI's knobs) change launch shapes of the baseline variants only;
     results stay correct for every combination."""
