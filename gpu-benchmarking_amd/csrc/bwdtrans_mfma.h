@@ -240,6 +240,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
             chunk_flush<GW, true, true>(slab, out + c * (uint64_t)(EC * G::NQT), evalid * G::NQT, lane);
         }
         wave_lds_fence(); // slab is rewritten by the next chunk's staging
+        if (n + 1 < it.count)
+            touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
     }
 }
 

@@ -1,0 +1,276 @@
+// bwdtrans_mfma4.h -- 2D quad BwdTrans on v_mfma_f64_4x4x4_4b_f64: the fp64 instruction MI355X runs fastest.
+//
+// Why this instruction (measured on the device, profiles/r02/mfma_fp64_rates_and_4x4x4_lane_map.log): with every SIMD
+// busy, v_mfma_f64_16x16x4_f64 sustains 33 / 46 / 48 TFLOP/s at 1 / 2 / 4 waves per SIMD, v_fma_f64 42 / 55 / 55, and
+// v_mfma_f64_4x4x4_4b_f64 69 / 72 / 68 -- 1.5x the 16x16x4 form and 1.3x the vector pipe, at full rate from ONE wave per
+// SIMD, and with a tile granularity of 4 instead of 16 (nm = 27 pads to 28, not 32).  The 16x16x4 kernel of
+// bwdtrans_mfma.h therefore sat at that instruction's own ceiling (45 TF/s issued at 2D nq = 32, "MFMA busy 0.68").
+// Replaces the same reference kernel, BwdTransQuadKernel_QP_1D (benchmark04/benchmark04.cc:353-426).
+//
+// The instruction is FOUR independent 4x4x4 products, D_b = A_b * B_b + C_b, b = 0..3.  Lane maps (found with one-hot
+// operands, same log), lane = 16*hi + 4*b + lo:
+//     A operand   A_b[row = lo][k = hi]
+//     B operand   B_b[k = hi][col = lo]
+//     C / D       D_b[row = hi][col = lo]
+// so a result register is directly the B operand of a product that contracts over ITS row index -- the chaining the
+// 16x16x4 kernel uses, at granularity 4:
+//     step 1   W[q][i]   = sum_p In[q][p] * B0[p][i]     A = In tile (LDS gather), B = B0 tile (LDS, zero padded)
+//     step 2   Out[j][i] = sum_q B1[q][j] * W[q][i]      A = B1 tile (LDS),        B = W  (step 1's accumulators)
+// The intermediate never leaves the registers.  The four blocks of an instruction are EB elements x IB = 4/EB
+// neighbouring i tiles (EB = 4: four elements, no tile slot is ever idle; EB = 2: two elements x two i tiles, half
+// the LDS footprint per wave; EB = 1: one element x four i tiles).  Operands that are the same for several blocks
+// (the In tile across i tiles, the basis tiles across elements) are LDS reads of one address by several lanes, which
+// the LDS broadcasts; the basis row stride keeps the basis gathers conflict free.  Padding rows / columns (p, q >= nm; i, j >= nq) meet zero
+// entries of the LDS basis copies; data indices are clamped into the element, so padding lanes read finite values.
+// The chunk's output is assembled in the slab (the input image is dead after step 1) and leaves as one flat
+// line-aligned 16-byte-per-lane stream (chunk_flush, bwdtrans_wave.h).
+#pragma once
+
+#include "bwdtrans_wave.h"
+
+namespace sf
+{
+
+// basis row stride (doubles): rows hi and hi+1 of a tile read 4*IB consecutive doubles each in one LDS pass, so the
+// stride must keep them 4*IB .. 32-4*IB doubles apart modulo the 32 8-byte banks
+constexpr int mfma4_basis_stride(int cols, int ib)
+{
+    int bs = cols;
+    while (bs % 32 < 4 * ib || bs % 32 > 32 - 4 * ib)
+        ++bs;
+    return bs;
+}
+
+template <int NQ, int EB> struct Mfma4Geom
+{
+    static_assert(EB == 1 || EB == 2 || EB == 4, "blocks = EB elements x 4/EB i tiles");
+    static constexpr int NM = NQ - 1, IB = 4 / EB;
+    static constexpr int NMT = NM * NM, NQT = NQ * NQ;
+    static constexpr int TQ = cdiv(NM, 4);  // q tiles = p steps = q steps
+    static constexpr int TI = cdiv(NQ, 4);  // i tiles = j tiles
+    static constexpr int TG = cdiv(TI, IB); // groups of IB i tiles (one instruction each)
+    static constexpr int NMP = 4 * TQ;      // basis rows held in LDS (zero beyond nm)
+    // The input image keeps the HBM layout (row stride nm, element stride nm^2): staging is then a flat 16-byte copy
+    // with no address arithmetic and no address registers.  The A gathers pay for it with 2-way (some orders 4-way)
+    // bank conflicts on ~100 two-cycle reads per chunk, against ~400 sixteen-cycle products; a padded image measured
+    // slower (the staging addresses, 2 per staging register, spilled and every chunk paid ~25 VALU per value).
+    static constexpr int S    = NM;
+    static constexpr int ESTR = NM * NM;
+    static constexpr int BS   = mfma4_basis_stride(4 * IB * TG, IB);
+    static constexpr int NBAS = NMP * BS;
+    static constexpr int SLAB0 = EB * ESTR > EB * NQT ? EB * ESTR : EB * NQT;
+    static constexpr int SLAB  = (SLAB0 + 1) & ~1; // doubles per wave
+};
+
+template <int NQ, int EB, int WPB> constexpr size_t mfma4_lds_bytes()
+{
+    using G = Mfma4Geom<NQ, EB>;
+    return sizeof(double) * (size_t)(2 * G::NBAS + WPB * G::SLAB);
+}
+
+// GJ: j tiles whose accumulators are live together in step 2 (register budget); KMAP: chunks per wave (chunk_iter,
+// bwdtrans_wave.h; 0 = persistent grid) -- a workgroup pays for its LDS basis copies once, so it should live for
+// several chunks; XG: XCD runs (sf_common.h)
+// STG: waves in odd hardware wave slots start STG*1024 cycles late.  Two waves of a SIMD that start together run the same
+// phases in lock step -- both in their matrix phase (sharing the pipe), then both in their load / store phase (pipe
+// idle) -- and a persistent loop never breaks the symmetry; a one-off stagger of about half a chunk period does.
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, int STG = 0>
+__global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
+    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
+    double *__restrict__ out, uint64_t nelmt)
+{
+    using G  = Mfma4Geom<NQ, EB>;
+    using GW = WaveGeom<NQ, EB, 2>; // chunk_load / chunk_flush geometry (IN_DBL, NLD, OUT_DBL)
+    constexpr int NM = G::NM, IB = G::IB, TQ = G::TQ, TI = G::TI, TG = G::TG, BS = G::BS;
+
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *bl0 = lds, *bl1 = lds + G::NBAS;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *slab   = lds + 2 * G::NBAS + wib * G::SLAB;
+    const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+    const int e = blk / IB, ib = blk % IB;
+
+    // zero-padded LDS copies of the two bases (once per workgroup); every load is requested before the first is used
+    {
+        constexpr int NIT = cdiv(G::NBAS, kWave * WPB);
+        double v0[NIT], v1[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+        {
+            const int x = k * kWave * WPB + (int)threadIdx.x;
+            const int p = x / BS, i = x - p * BS;
+            const bool real = p < NM && i < NQ;
+            v0[k] = real ? b0[p * NQ + i] : 0.0;
+            v1[k] = real ? b1[p * NQ + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+        {
+            const int x = k * kWave * WPB + (int)threadIdx.x;
+            if (x < G::NBAS)
+            {
+                bl0[x] = v0[k];
+                bl1[x] = v1[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint64_t nchunk = (nelmt + EB - 1) / EB;
+    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
+    if (it.count == 0)
+        return;
+    if constexpr (STG > 0)
+    {
+        // HW_ID (hwreg 4) bits 3:0 = wave slot within the SIMD
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
+        if (slot & 1)
+        {
+#pragma unroll 1
+            for (int k = 0; k < STG; ++k)
+                __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles
+        }
+    }
+    typename GW::Vec st[GW::NLD];
+    chunk_fetch<GW, EB>(st, in, it.first, nelmt, lane);
+
+    uint64_t c = it.first;
+    for (uint64_t n = 0; n < it.count; ++n, c += it.step)
+    {
+    const uint64_t left = nelmt - c * EB;
+    const int evalid    = left >= (uint64_t)EB ? EB : (int)left;
+
+    // ---- chunk: staging registers -> LDS image (HBM layout: flat copy); then request the next chunk -----------------
+    if constexpr (GW::VEC2)
+    {
+#pragma unroll
+        for (int k = 0; k < GW::NLD; ++k)
+        {
+            const int v = k * kWave + lane;
+            if ((k + 1) * kWave <= GW::IN_DBL / 2 || v < GW::IN_DBL / 2)
+                *reinterpret_cast<double2_t *>(slab + 2 * v) = st[k];
+        }
+    }
+    else
+    {
+        const int sh = line_offset<double>(in + c * GW::IN_DBL);
+#pragma unroll
+        for (int k = 0; k < word_grid_regs<GW::IN_DBL, double>(); ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+            {
+                const int f = 2 * (k * kWave + lane) - sh + h;
+                if (f >= 0 && f < GW::IN_DBL)
+                    slab[f] = st[k][h];
+            }
+    }
+    wave_lds_fence();
+    if (n + 1 < it.count)
+        chunk_fetch<GW, EB>(st, in, c + it.step, nelmt, lane);
+
+    // ---- step 1: W[q][i] = sum_p In[q][p] B0[p][i]; D = W[q on hi][i on lo] of block (e, ib) ---------------------
+    double w[TQ][TG];
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+        for (int ig = 0; ig < TG; ++ig)
+            w[tq][ig] = 0.0;
+    {
+        int arow[TQ];
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq)
+        {
+            const int q = 4 * tq + lo;
+            arow[tq]    = e * G::ESTR + (q < NM ? q : NM - 1) * G::S;
+        }
+        const double *btile = bl0 + hi * BS + 4 * ib + lo;
+        // operands of p step tp+1 are requested before the products of step tp are issued: an LDS read takes longer
+        // than the few 16-cycle products that consume it, and hipcc does not move it up by itself
+        double a1[2][TQ], bt[2][TG];
+        auto request = [&](int buf, int tp) {
+            const int p  = 4 * tp + hi;
+            const int pc = p < NM ? p : NM - 1;
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq)
+                a1[buf][tq] = slab[arow[tq] + pc];
+#pragma unroll
+            for (int ig = 0; ig < TG; ++ig)
+                bt[buf][ig] = btile[4 * tp * BS + 4 * IB * ig];
+        };
+        request(0, 0);
+#pragma unroll
+        for (int tp = 0; tp < TQ; ++tp)
+        {
+            if (tp + 1 < TQ)
+                request((tp + 1) & 1, tp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ig = 0; ig < TG; ++ig)
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+                    w[tq][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[tp & 1][tq], bt[tp & 1][ig], w[tq][ig], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
+
+    // ---- step 2: Out[j][i] = sum_q B1[q][j] W[q][i]; D = Out[j on hi][i on lo] ------------------------------------
+    {
+        const double *atile = bl1 + hi * BS + lo;
+        double *oimg        = slab + e * G::NQT + hi * NQ + 4 * ib + lo;
+#pragma unroll
+        for (int j0 = 0; j0 < TI; j0 += GJ)
+        {
+            double o[GJ][TG];
+#pragma unroll
+            for (int t = 0; t < GJ; ++t)
+#pragma unroll
+                for (int ig = 0; ig < TG; ++ig)
+                    o[t][ig] = 0.0;
+            double a2[2][GJ];
+            auto request = [&](int buf, int tq) {
+#pragma unroll
+                for (int t = 0; t < GJ; ++t)
+                    if (j0 + t < TI)
+                        a2[buf][t] = atile[4 * tq * BS + 4 * (j0 + t)];
+            };
+            request(0, 0);
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq)
+            {
+                if (tq + 1 < TQ)
+                    request((tq + 1) & 1, tq + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < GJ; ++t)
+                {
+                    if (j0 + t >= TI)
+                        continue;
+#pragma unroll
+                    for (int ig = 0; ig < TG; ++ig)
+                        o[t][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[tq & 1][t], w[tq][ig], o[t][ig], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < GJ; ++t)
+#pragma unroll
+                for (int ig = 0; ig < TG; ++ig)
+                {
+                    const int tj = j0 + t;
+                    if (tj < TI && 4 * tj + hi < NQ && 4 * (IB * ig + ib) + lo < NQ)
+                        oimg[4 * tj * NQ + 4 * IB * ig] = o[t][ig];
+                }
+        }
+    }
+    wave_lds_fence();
+    // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
+    chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
+    wave_lds_fence(); // the slab is rewritten by the next chunk's staging
+    if (n + 1 < it.count)
+        touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
+    }
+}
+
+} // namespace sf

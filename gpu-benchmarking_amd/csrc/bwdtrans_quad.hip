@@ -117,7 +117,47 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
     }
 }
 
-// Orders for which SF_VARIANT_AUTO prefers the matrix-core kernel: nq >= 25.  On MI355X the fp64 matrix and vector
+// 4x4x4_4b matrix-core kernel (bwdtrans_mfma4.h), every order 8..32.  Configuration per order from
+// profiles/r02/tune_mfma4_<nq>.log (1 Mi elements, mean of 10 launches, fraction of the 8 TB/s HBM roofline; in brackets
+// the better of the wave kernel and the 16x16x4 kernel on the same box):
+//   21 0.704 (0.697)  22 0.666 (0.625)  23 0.686 (0.612)  24 0.695 (0.583)  25 0.651 (0.593)  26 0.641 (0.570)
+//   27 0.662 (0.575)  28 0.667 (0.602)  29 0.643 (0.595)  30 0.625 (0.583)  31 0.633 (0.611)  32 0.659 (0.696)
+// Up to nq = 24 short-lived workgroups (one chunk per wave) are ahead -- the hardware dispatcher keeps the DRAM front
+// tight, as for the wave kernels; from 25 the per-workgroup prologue (LDS copies of both bases, one barrier) and the
+// unhidden load of a one-chunk wave cost more than that, and a persistent grid with register prefetch wins.
+template <int NQ> static int go_mfma4(const QuadArgs &a, hipStream_t s)
+{
+    if constexpr (NQ <= 22 || NQ == 24)
+        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 1, 64>(a, s); // two elements x two i tiles, one chunk per wave
+    else if constexpr (NQ == 23 || (NQ >= 26 && NQ <= 28))
+        return launch_quad_mfma4<NQ, 4, 4, 1, 4, 0, 0>(a, s); // four elements per instruction, persistent
+    else if constexpr (NQ == 31 || NQ == 32)
+        return launch_quad_mfma4<NQ, 2, 8, 2, 4, 0, 0>(a, s);
+    else
+        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 0, 0>(a, s); // 25, 29, 30
+}
+
+int launch_quad_mfma4_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
+{
+    switch (nq)
+    {
+#define SF_CASE(N) case N: return go_mfma4<N>(a, s);
+        SF_CASE(8) SF_CASE(9) SF_CASE(10) SF_CASE(11) SF_CASE(12) SF_CASE(13) SF_CASE(14) SF_CASE(15) SF_CASE(16)
+        SF_CASE(17) SF_CASE(18) SF_CASE(19) SF_CASE(20) SF_CASE(21) SF_CASE(22) SF_CASE(23) SF_CASE(24)
+        SF_CASE(25) SF_CASE(26) SF_CASE(27) SF_CASE(28) SF_CASE(29) SF_CASE(30) SF_CASE(31) SF_CASE(32)
+#undef SF_CASE
+    default: return SF_ENOTBUILT;
+    }
+}
+
+// What SF_VARIANT_AUTO runs in 2D: wave kernel up to nq = 20, the 4x4x4_4b matrix-core kernel for 21..31, the 16x16x4
+// matrix-core kernel at 32 (exact 16-wide tiles there), wave kernel again for whatever else is in its table.
+int quad_auto_kernel(unsigned nq)
+{
+    return nq >= 21 && nq <= 31 ? SF_VARIANT_MFMA4 : (nq == 32 ? SF_VARIANT_MFMA : SF_VARIANT_WAVE);
+}
+
+// Orders for which the 16x16x4 kernel is ahead of the wave kernel (kept for the record: AUTO no longer asks): nq >= 25.  On MI355X the fp64 matrix and vector
 // pipes have the same peak, so the exact-size FMAs of the wave kernel win wherever their operands can be fed; with
 // scalar-register basis blocks, four-element chunks and XCD runs that is every order up to 24 (349 / 355 / 358 / 359 /
 // 366 GDOF/s at nq = 12 .. 16 against 344 / 341 / 341 / 336 / 347 on the matrix cores,

@@ -240,6 +240,19 @@ __device__ __forceinline__ void chunk_load_any_f64(double2_t (&st)[NREG], const 
     chunk_load_any<NMAX, NREG, double>(st, src, lane, nvalid);
 }
 
+// A chunk loop requests chunk n+1 (loads into the staging registers), computes chunk n and stores it, then loops.
+// Left alone, the wait for the staging registers lands at the loop header, where hipcc no longer knows how many
+// stores were issued after the loads and emits s_waitcnt vmcnt(0): every wave then also waits for its own stores to
+// reach memory before it may touch the next chunk.  Touching the staging registers at the END of the iteration, in
+// the block that issued the stores, lets the counter be exact (vmcnt(number of stores): memory operations of a wave
+// retire in order) and the header needs no wait at all.
+template <typename V, int N> __device__ __forceinline__ void touch_staged(V (&st)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        asm volatile("" : "+v"(st[k]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // chunk load: global -> staging registers (issued one chunk ahead of its use)
 // ------------------------------------------------------------------------------------------------

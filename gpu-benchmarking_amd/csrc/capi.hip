@@ -37,7 +37,7 @@ const char *sf_error_string(int rc)
 const char *sf_variant_name(int variant)
 {
     static const char *names[SF_NUM_VARIANTS] = {"auto",      "wave",    "thread", "block-lds",
-                                                 "block-glb", "generic", "mfma"};
+                                                 "block-glb", "generic", "mfma",   "mfma4"};
     return (variant >= 0 && variant < SF_NUM_VARIANTS) ? names[variant] : "?";
 }
 
@@ -127,8 +127,10 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
     {
         if (iso && vec_ok)
         {
-            // high order is compute-bound on the vector ALUs: matrix cores first
-            int rc = quad_prefers_mfma(nq0) ? launch_quad_mfma_nq(nq0, a, s) : SF_ENOTBUILT;
+            // the measured best kernel of the order first (bwdtrans_quad.hip), then whatever else is built for it
+            const int first = quad_auto_kernel(nq0);
+            int rc = first == SF_VARIANT_MFMA4 ? launch_quad_mfma4_nq(nq0, a, s)
+                                               : (first == SF_VARIANT_MFMA ? launch_quad_mfma_nq(nq0, a, s) : SF_ENOTBUILT);
             if (rc == SF_ENOTBUILT)
                 rc = launch_quad_wave_nq(nq0, a, s);
             if (rc == SF_ENOTBUILT)
@@ -150,6 +152,12 @@ int sf_bwdtrans_quad_f64_variant(int variant, unsigned nq0, unsigned nq1, size_t
         if (!vec_ok)
             return SF_EALIGN;
         return launch_quad_mfma_nq(nq0, a, s);
+    case SF_VARIANT_MFMA4:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_quad_mfma4_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
         return launch_quad_generic(SF_VARIANT_GENERIC, nq0, nq1, a, s);
     case SF_VARIANT_THREAD:

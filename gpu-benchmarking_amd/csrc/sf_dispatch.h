@@ -13,7 +13,9 @@ int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
+int launch_quad_mfma4_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 bool quad_prefers_mfma(unsigned nq);
+int quad_auto_kernel(unsigned nq);
 int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
                        hipStream_t s);
 int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);

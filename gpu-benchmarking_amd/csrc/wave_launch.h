@@ -2,6 +2,7 @@
 #pragma once
 
 #include "bwdtrans_mfma.h"
+#include "bwdtrans_mfma4.h"
 #include "bwdtrans_wave.h"
 
 namespace sf
@@ -99,6 +100,28 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
     if (grid_override > 0)
         grid = (uint64_t)grid_override;
+    if (grid > need || KMAP != 0)
+        grid = need;
+    if (grid > 0x7fffffffull)
+        return SF_EINVAL;
+    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, int STG = 0>
+inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
+{
+    static int cache[kMaxDev] = {};
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, STG>;
+    constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB>();
+    static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t nchunk = (a.nelmt + EB - 1) / EB;
+    const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
+    const uint64_t need   = (nchunk + per - 1) / per;
+    uint64_t grid         = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache); // also raises the LDS limit
     if (grid > need || KMAP != 0)
         grid = need;
     if (grid > 0x7fffffffull)

@@ -1,0 +1,144 @@
+// sf_tune_mfma4.hip -- configuration sweep of the 4x4x4_4b matrix-core kernel (bwdtrans_mfma4.h) against the shipped
+// AUTO kernel of the same order (development tool).  Built per order: -DTUNE_NQ=N.  Usage: sf_tune_mfma4_N [nelmt] [reps]
+#include "../csrc/sf_dispatch.h"
+#include "../csrc/wave_launch.h"
+#include "tune_guard.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#ifndef TUNE_NQ
+#define TUNE_NQ 28
+#endif
+
+using namespace sf;
+
+#define CK(x)                                                                                      \
+    do                                                                                             \
+    {                                                                                              \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+        {                                                                                          \
+            std::fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__);    \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+
+static int g_reps = 15;
+static hipEvent_t g_e0, g_e1;
+static double *g_ref; // output of the reference variant, for a max-abs-difference check
+static size_t g_nout;
+
+__global__ void maxdiff_kernel(const double *a, const double *b, size_t n, double *res)
+{
+    double m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const double d = fabs(a[i] - b[i]);
+        m              = fmax(m, d == d ? d : 1e300); // NaN (an output nobody wrote) must not hide
+    }
+    for (int off = 32; off; off >>= 1)
+        m = fmax(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax((unsigned long long *)res, (unsigned long long)__double_as_longlong(m)); // m >= 0: order-preserving
+}
+
+template <class F> static void run(const char *label, const QuadArgs &a, F launch, bool is_ref = false)
+{
+    const int NQ = TUNE_NQ;
+    const double nm = NQ - 1;
+    if (!tune::fits(label, sizeof(double) * a.nelmt * (NQ - 1) * (NQ - 1), sizeof(double) * a.nelmt * NQ * NQ,
+                    sizeof(double) * (NQ - 1) * NQ))
+        return;
+    CK(hipMemset(a.out, 0xff, sizeof(double) * g_nout)); // NaN pattern: unwritten outputs show up in the check
+    int rc = launch();
+    CK(hipDeviceSynchronize());
+    if (rc != 0)
+    {
+        std::printf("%-44s rc=%d\n", label, rc);
+        return;
+    }
+    double *dres, hres = 0;
+    CK(hipMalloc((void **)&dres, sizeof(double)));
+    CK(hipMemset(dres, 0, sizeof(double)));
+    if (is_ref)
+        CK(hipMemcpy(g_ref, a.out, sizeof(double) * g_nout, hipMemcpyDeviceToDevice));
+    maxdiff_kernel<<<1024, 256>>>(a.out, g_ref, g_nout, dres);
+    CK(hipMemcpy(&hres, dres, sizeof(double), hipMemcpyDeviceToHost));
+    CK(hipFree(dres));
+    std::vector<double> t;
+    for (int r = 0; r < g_reps; ++r)
+    {
+        CK(hipEventRecord(g_e0, 0));
+        launch();
+        CK(hipEventRecord(g_e1, 0));
+        CK(hipEventSynchronize(g_e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+        t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    double sum = 0;
+    for (double v : t)
+        sum += v;
+    const double tmin = t[0], tmean = sum / t.size();
+    const double dof = a.nelmt * nm * nm, bytes = a.nelmt * 8.0 * (nm * nm + (double)NQ * NQ);
+    std::printf("%-44s min %8.4f mean %8.4f ms | %7.2f / %7.2f GDOF/s | %7.1f GB/s = %.3f of 8 TB/s (mean) | max|d| %.2e\n",
+                label, tmin, tmean, dof / (tmin * 1e-3) * 1e-9, dof / (tmean * 1e-3) * 1e-9,
+                bytes / (tmean * 1e-3) * 1e-9, bytes / (tmean * 1e-3) * 1e-9 / 8000.0, hres);
+    std::fflush(stdout);
+}
+
+template <int EB, int WPB, int MW, int GJ, int K, int XG, int STG = 0> static void m4(const QuadArgs &a)
+{
+    constexpr int NQ = TUNE_NQ;
+    if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
+    {
+        char label[96];
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d stg%d lds %zu", NQ, EB, WPB, MW, GJ, K, XG, STG,
+                      mfma4_lds_bytes<NQ, EB, WPB>());
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, STG>(a, 0); });
+    }
+}
+
+int main(int argc, char **argv)
+{
+    constexpr int NQ = TUNE_NQ, NM = NQ - 1;
+    const size_t nelmt = argc > 1 ? (size_t)std::atoll(argv[1]) : (size_t)1 << 20;
+    g_reps             = argc > 2 ? std::atoi(argv[2]) : 15;
+    CK(hipEventCreate(&g_e0));
+    CK(hipEventCreate(&g_e1));
+    double *b0, *b1, *in, *out;
+    g_nout = nelmt * NQ * NQ;
+    CK(hipMalloc((void **)&b0, sizeof(double) * NM * NQ));
+    CK(hipMalloc((void **)&b1, sizeof(double) * NM * NQ));
+    CK(hipMalloc((void **)&in, sizeof(double) * nelmt * NM * NM));
+    CK(hipMalloc((void **)&out, sizeof(double) * g_nout));
+    CK(hipMalloc((void **)&g_ref, sizeof(double) * g_nout));
+    tune::capacity() = {sizeof(double) * nelmt * NM * NM, sizeof(double) * g_nout, sizeof(double) * NM * NQ};
+    fill_random(b0, NM * NQ, 11, 0, 0);
+    fill_random(b1, NM * NQ, 12, 0, 0);
+    fill_random(in, nelmt * NM * NM, 0x5F3759DF, 0, 0);
+    CK(hipDeviceSynchronize());
+    QuadArgs a{b0, b1, in, nullptr, out, nelmt};
+    std::printf("nq %d, %zu elements, %d reps; reference = the generic LDS kernel (first row), then the shipped kernels\n",
+                NQ, nelmt, g_reps);
+    run("generic block/LDS (reference result)", a, [&]() { return launch_quad_generic(SF_VARIANT_BLOCK_LDS, NQ, NQ, a, 0); },
+        true);
+    for (int rep = 0; rep < 2; ++rep)
+    {
+        run("shipped wave kernel", a, [&]() { return launch_quad_wave_nq(NQ, a, 0); });
+        run("shipped 16x16x4 matrix-core kernel", a, [&]() { return launch_quad_mfma_nq(NQ, a, 0); });
+        m4<2, 4, 2, 4, 1, 64>(a);
+        m4<2, 4, 2, 4, 4, 64>(a);
+        m4<2, 8, 2, 4, 4, 64>(a);
+        m4<2, 4, 2, 4, 0, 0>(a);
+        m4<2, 8, 2, 4, 0, 0>(a);
+        m4<4, 4, 1, 4, 0, 0>(a);
+        m4<4, 2, 1, 4, 4, 64>(a);
+    }
+    return 0;
+}

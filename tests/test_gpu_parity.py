@@ -79,6 +79,22 @@ def test_quad_mfma_parity_all_orders(sf, oracle, nq):
         assert err <= TOL, (nq, nelmt, err)
 
 
+@pytest.mark.parametrize("nq", range(8, 33))
+def test_quad_mfma4_parity_all_orders(sf, oracle, nq):
+    """v_mfma_f64_4x4x4_4b kernel (tile granularity 4; AUTO runs it at nq 21..31): every order it is built for, ragged
+    counts around its 1 / 2 / 4-element chunks and its one-chunk, several-chunk and persistent wave mappings."""
+    for nelmt in (1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 129, 1000, 4099):
+        err = _quad_case(sf, oracle, (nq, nq), nelmt, "mfma4", seed=nelmt + nq)
+        assert err <= TOL, (nq, nelmt, err)
+    # more chunks than a persistent grid has waves (256 CUs x 4..8 waves), ragged tail, sin/cos basis
+    nelmt = 70001 if nq <= 24 else 20011
+    b = sf.fill_basis(nq - 1, nq)
+    x = sf.fill_random(nelmt * (nq - 1) ** 2, 77 + nq)
+    got = sf.bwdtrans_quad((nq, nq), b, b, x, variant="mfma4")
+    ref = oracle.bwdtrans_quad((nq, nq), nelmt, _np(b), _np(b), _np(x))
+    assert oracle.rel_err(_np(got), ref) <= TOL
+
+
 @pytest.mark.parametrize("nq", range(4, 17))
 def test_hex_mfma_parity_all_orders(sf, oracle, nq):
     """3D matrix-core kernel: three chained v_mfma_f64_16x16x4 GEMMs, every order it is built for
@@ -102,6 +118,13 @@ def test_mfma_not_built_cases(sf):
     x2 = sf.fill_random(49 * 4, 1)
     with pytest.raises(capi.SumfactError) as ei:
         sf.bwdtrans_quad((8, 8), b, b, x2, variant="mfma")
+    assert ei.value.rc == capi.SF_ENOTBUILT
+    b7 = sf.fill_basis(6, 7)
+    with pytest.raises(capi.SumfactError) as ei:
+        sf.bwdtrans_quad((7, 7), b7, b7, sf.fill_random(36 * 4, 1), variant="mfma4")
+    assert ei.value.rc == capi.SF_ENOTBUILT
+    with pytest.raises(capi.SumfactError) as ei:                      # 2D-only kernel
+        sf.bwdtrans_hex((8, 8, 8), b, b, b, sf.fill_random(343 * 4, 1), variant="mfma4")
     assert ei.value.rc == capi.SF_ENOTBUILT
 
 
