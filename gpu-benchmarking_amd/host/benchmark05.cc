@@ -18,15 +18,57 @@
 // the flagship kernels pick their own launch shapes.
 // Extra options go AFTER the positional ones: --nelmt N, --data sincos|random, --json FILE,
 // --no-baselines, --seed S, --variant auto|wave|mfma (kernel behind column 4), --precision f64|f32
-// (f32 = the T = float instantiation the reference's templates allow: flagship column only).
+// (f32 = the T = float instantiation the reference's templates allow: flagship column only),
+// --ngpus N (aggregate row: the batch sharded over N devices of this node, one process, RCCL for MAX(time) /
+// SUM(sum of squares), host/multigpu.h; only the flagship column is run, the others print 0).
 #include "harness.h"
+#include "multigpu.h"
 
+#include <memory>
 #include <type_traits>
 
 using namespace harness;
 
 static Options g_opt;
 static JsonLog g_json;
+static std::unique_ptr<MultiGpu> g_multi;
+
+// --ngpus N: same three lines, flagship column = total DOF / MAX over devices of the device's best kernel time
+static void run_test_multi(const unsigned int size, const unsigned nq0, const unsigned nq1, const unsigned nq2)
+{
+    const size_t nelmt = size;
+    const size_t nmTot = (size_t)(nq0 - 1) * (nq1 - 1) * (nq2 - 1), nqTot = (size_t)nq0 * nq1 * nq2;
+    const MultiGpuResult r =
+        run_hex_multi(*g_multi, nelmt, nq0, nq1, nq2, g_opt.variant, g_opt.data == "random", g_opt.seed);
+    const char *names[6] = {"HIP (thread/elmt)", "HIP (block/elmt glb)", "HIP (block/elmt LDS)",
+                            "HIP (wave/chunk)", "rocBLAS", "HIP (thread/elmt il64)"};
+    const double dofs = 1.0e-9 * nelmt * (double)nmTot / r.t_max_event_s;
+    std::cout << std::setprecision(10);
+    std::cout << "nelmt " << nelmt << " Case:";
+    for (int v = 0; v < 6; ++v)
+        std::cout << " " << names[v];
+    std::cout << std::endl;
+    std::cout << "nelmt " << nelmt << " norm: ";
+    for (int v = 0; v < 6; ++v)
+        std::cout << (v ? "     " : "") << (v == 3 ? std::sqrt(r.sumsq) : 0.0);
+    std::cout << std::endl;
+    std::cout << "nelmt " << nelmt << " DOF/s: ";
+    for (int v = 0; v < 6; ++v)
+        std::cout << (v ? "     " : "") << (v == 3 ? dofs : 0.0);
+    std::cout << std::endl << std::flush;
+    const double bytes = 8.0 * nelmt * (double)(nmTot + nqTot);
+    std::ostringstream j;
+    j << std::setprecision(10) << "{\"nelmt\": " << nelmt << ", \"nq\": [" << nq0 << "," << nq1 << "," << nq2
+      << "], \"ngpus\": " << g_multi->size() << ", \"wave_gdof_s\": " << dofs
+      << ", \"wave_gdof_s_host_wall\": " << 1.0e-9 * nelmt * (double)nmTot / r.t_wall_s
+      << ", \"wave_gb_s\": " << 1.0e-9 * bytes / r.t_max_event_s
+      << ", \"wave_frac_hbm_roofline_per_gpu\": " << 1.0e-9 * bytes / r.t_max_event_s / kHbmPeakGBs / g_multi->size()
+      << ", \"per_device_ms\": [";
+    for (size_t g = 0; g < r.per_device_s.size(); ++g)
+        j << (g ? ", " : "") << 1e3 * r.per_device_s[g];
+    j << "], \"norm\": " << std::sqrt(r.sumsq) << "}";
+    g_json.row(j.str());
+}
 
 template <typename T>
 void run_test(const unsigned int size, const unsigned int _nq0, const unsigned int _nq1,
@@ -195,6 +237,38 @@ int main(int argc, char **argv)
         return 4;
     }
     const bool f32 = (g_opt.precision == "f32");
+    if (g_opt.ngpus > 1 || getenv("SF_FORCE_MULTIGPU_PATH"))
+    {
+        int ndev = 0;
+        HIP_CHECK(hipGetDeviceCount(&ndev));
+        if (ndev < g_opt.ngpus)
+        {
+            std::cerr << "benchmark05: --ngpus " << g_opt.ngpus << " but this node shows " << ndev
+                      << " device(s); refusing to print an aggregate row for fewer GPUs" << std::endl;
+            return 5;
+        }
+        if (f32)
+        {
+            std::cerr << "benchmark05: --ngpus runs the fp64 flagship only" << std::endl;
+            return 1;
+        }
+        g_multi.reset(new MultiGpu(g_opt.ngpus));
+        std::cout << "BwdTrans on " << g_opt.ngpus << " GPU(s): element ranges, RCCL MAX(time) / SUM(norm^2)" << std::endl;
+        if (g_opt.nelmt > 0)
+            run_test_multi((unsigned)g_opt.nelmt, nq0, nq1, nq2);
+        else
+            for (unsigned int size = 2 << 6; size < 2 << 20; size <<= 1)
+            {
+                if (g_opt.maxsize > 0 && size > g_opt.maxsize)
+                    break;
+                run_test_multi(size, nq0, nq1, nq2);
+            }
+        g_json.write(g_opt.json, device_header() + ", \"benchmark\": \"benchmark05\", \"ngpus\": " +
+                                     std::to_string(g_opt.ngpus));
+        g_multi.reset();
+        (void)sf_shutdown();
+        return 0;
+    }
     if (g_opt.nelmt > 0)
     {
         if (f32)

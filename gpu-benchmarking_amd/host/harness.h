@@ -137,6 +137,7 @@ struct Options
     int variant       = SF_VARIANT_AUTO; // --variant auto|wave|mfma|... : kernel of the flagship column
     unsigned seed     = 0x5F3759DFu;
     std::string precision = "f64"; // --precision f64|f32
+    int ngpus = 1;               // --ngpus N : benchmark05's aggregate row over N devices of this node (multigpu.h)
 };
 
 inline Options parse(int argc, char **argv)
@@ -168,6 +169,15 @@ inline Options parse(int argc, char **argv)
             o.baselines = false;
         else if (s == "--precision")
             o.precision = next("--precision");
+        else if (s == "--ngpus")
+        {
+            o.ngpus = std::atoi(next("--ngpus").c_str());
+            if (o.ngpus < 1 || o.ngpus > 64)
+            {
+                std::cerr << "--ngpus needs a device count between 1 and 64" << std::endl;
+                std::exit(1);
+            }
+        }
         else if (s == "--variant")
         {
             const std::string v = next("--variant");

@@ -180,3 +180,46 @@ def test_benchmark05_fp32_above_the_fp64_tables(pkg, oracle):
     ref = oracle.bwdtrans_hex((14,) * 3, 4096, b, b, b, oracle.fill_sincos(4096, 13 ** 3))
     norm = math.sqrt(oracle.sumsq(ref))
     assert abs(log.norms[0][3] - norm) <= 5e-5 * norm and log.values[0][3] > 50.0
+
+
+def test_c99_consumer_of_the_boundary(pkg):
+    """examples/consumer.c: C99, built with gcc against include/sumfact.h + libsumfact.so + libamdhip64 (INTEGRATION.md
+    s1 as written): hipMalloc -> sf_fill_* -> sf_bwdtrans_hex_f64 -> sf_sumsq_f64 reproduces the reference's published
+    norm 17134.76235 (benchmark05/nq8x8x8.log:45) and exits 0."""
+    exe = os.path.join(ROOT, "examples", "consumer")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "-s", "consumer"], check=True)
+    out = _run([exe])
+    assert out.split() == ["nelmt", "1048576", "norm:", "17134.76235"]
+
+
+def test_benchmark05_ngpus_row(pkg, golden, tmp_path):
+    """`--ngpus N`: one process, N devices, RCCL MAX(time) / SUM(sum of squares) (host/multigpu.h).  This box has one
+    GPU: N = the device count runs the whole multi-device path (communicator, streams, shard ranges, both
+    all-reduces) and must reproduce the published norm; N above the device count refuses with exit code 5 instead of
+    printing an aggregate row for fewer GPUs."""
+    import torch
+    ndev = torch.cuda.device_count()
+    js = tmp_path / "multi.json"
+    env = dict(os.environ, SF_FORCE_MULTIGPU_PATH="1")
+    res = subprocess.run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "--nelmt", "1048576", "--ngpus", str(ndev),
+                          "--json", str(js)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    log = pkg.logfmt.parse_log(res.stdout)
+    assert log.ncols == 6 and log.sizes == [1048576.0]
+    assert abs(log.norms[0][3] - 17134.76235) <= 5.5e-10 * 17134.76235       # benchmark05/nq8x8x8.log:45
+    assert log.values[0][3] > 100.0 * ndev and all(v == 0.0 for i, v in enumerate(log.values[0]) if i != 3)
+    rec = json.loads(js.read_text())
+    assert rec["ngpus"] == ndev and len(rec["rows"][0]["per_device_ms"]) == ndev
+    # seeded data is generated from the global element index: the sharded norm equals the one-GPU norm
+    res = subprocess.run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "--nelmt", "300001", "--ngpus", str(ndev),
+                          "--data", "random"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    import math
+    x = pkg.fill_random(300001 * 343, 0x5F3759DF, 0)
+    b = pkg.fill_basis(7, 8)
+    want = math.sqrt(pkg.sumsq(pkg.bwdtrans_hex((8, 8, 8), b, b, b, x)))
+    got = pkg.logfmt.parse_log(res.stdout).norms[0][3]
+    assert abs(got - want) <= 5.5e-10 * want
+    res = subprocess.run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "--nelmt", "1000", "--ngpus", str(ndev + 1)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 5 and "refusing" in res.stderr

@@ -104,3 +104,17 @@ def test_postprocess_plots(pkg, golden, tmp_path):
     assert png.endswith("nq8x8x8.png") and os.path.getsize(png) > 1000
     assert abs(pp.roofline_gdofs("BwdTrans (NQ = 8, 8, 8)") - 401.17) < 0.01
     assert abs(pp.roofline_gdofs("BwdTrans (NQ = 8, 8)") - 433.63) < 0.01
+
+
+def test_ngpus_argument_is_validated_before_any_gpu_call():
+    """`benchmark05 --ngpus 0` / a non-number: exit 1 with a message, on a box with or without a GPU."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-benchmarking_amd", "bin",
+                       "benchmark05")
+    if not os.path.exists(exe):
+        import pytest
+        pytest.skip("drivers not built")
+    for bad in ("0", "x", "65"):
+        res = subprocess.run([exe, "8", "8", "8", "--ngpus", bad], capture_output=True, text=True, timeout=60)
+        assert res.returncode == 1 and "--ngpus" in res.stderr
