@@ -326,7 +326,7 @@ def main():
                                            "ok": abs(norm - GOLDEN_NORM_1M) <= 5.5e-10 * norm}
             del xs, os_
         if not args.no_extra:
-            result["extra"] = extras(sf, torch, dev)
+            result["extra"] = extras(sf, torch, dev, shard)
             fr = [v["frac"] for v in result["extra"]["hex_sweep"].values()]
             worst = min(result["extra"]["hex_sweep"].items(), key=lambda kv: kv[1]["frac"])
             result["roofline"]["sweep_min"] = round(min(fr), 4)
@@ -367,7 +367,14 @@ def measured_stream_gbs(sf, torch, dev, n=1 << 28, reps=10):
     return 24.0 * n / best * 1e-6
 
 
-def extras(sf, torch, dev, nelmt=1 << 20, reps=40):
+def traffic_ratio(shard, dim, nq, nelmt):
+    """Measured HBM bytes / algorithmic bytes of this shape from the committed PMC passes (None: not recorded, or
+    recorded on other kernel sources)."""
+    rec = shard.recorded_traffic(ROOT, dim, nq, nelmt)
+    return rec["over_algorithmic"] if rec and "STALE" not in rec["source"] else None
+
+
+def extras(sf, torch, dev, shard, nelmt=1 << 20, reps=40):
     """BASELINE configs 1 and 3 on one GPU: the hex nq = 2..10 sweep and the quad orders of the reference's
     run.sh (+ 20 / 24 / 28), min of `reps` groups (the reference's n_tests = 40; HIP events), each with its
     fraction of the 8 TB/s HBM roofline."""
@@ -418,7 +425,8 @@ def extras(sf, torch, dev, nelmt=1 << 20, reps=40):
         ms = best_ms(lambda: sf.bwdtrans_hex((nq,) * 3, b, b, b, x, out=o))
         gbs = nelmt * 8 * (nm ** 3 + nq ** 3) / ms * 1e-6
         out["hex_sweep"][str(nq)] = {"gdof_s": round(nelmt * nm ** 3 / ms * 1e-6, 2),
-                                     "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                                     "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                     "traffic_over_algorithmic": traffic_ratio(shard, 3, nq, nelmt)}
         del x, o
     for nq in QUAD_ORDERS:
         nm = nq - 1
@@ -428,7 +436,8 @@ def extras(sf, torch, dev, nelmt=1 << 20, reps=40):
         ms = best_ms(lambda: sf.bwdtrans_quad((nq, nq), b, b, x, out=o))
         gbs = nelmt * 8 * (nm ** 2 + nq ** 2) / ms * 1e-6
         out["quad"][str(nq)] = {"gdof_s": round(nelmt * nm ** 2 / ms * 1e-6, 2),
-                                "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                                "gb_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                "traffic_over_algorithmic": traffic_ratio(shard, 2, nq, nelmt)}
     out["hip_graph_replay"] = used_graph[0]
     return out
 

@@ -10,6 +10,8 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 
 def main(prof, rnd):
     dst = f"profiles/r{int(rnd):02d}"
@@ -36,17 +38,22 @@ def main(prof, rnd):
     fetch_b = summ["FETCH_SIZE"]["mean_kb"] * 1024 * 2  # gfx950: 128-B requests tallied at 64 B -> x2
     write_b = summ["WRITE_SIZE"]["mean_kb"] * 1024
     alg = nelmt * 8 * ((nq - 1) ** 3 + nq ** 3)
-    rec = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py "
-                   "--steps 5 --warmup 1` (tools/collect_profiles.sh); values are KB per dispatch of "
-                   "sf::hex_wave_kernel; FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM "
-                   "section) prescribes for 16-B-per-lane streaming reads on gfx950; WRITE_SIZE taken as is.",
-           "round": int(rnd),
-           "rows": [{"dim": 3, "nq": nq, "nelmt": nelmt, "fetch_size_kb_raw": summ["FETCH_SIZE"],
-                     "write_size_kb_raw": summ["WRITE_SIZE"], "hbm_read_bytes": round(fetch_b),
-                     "hbm_write_bytes": round(write_b), "hbm_bytes_per_launch": round(fetch_b + write_b),
-                     "algorithmic_bytes_per_launch": alg,
-                     "traffic_over_algorithmic": round((fetch_b + write_b) / alg, 4)}]}
-    json.dump(rec, open("profiles/hbm_traffic.json", "w"), indent=1)
+    # one row of profiles/hbm_traffic.json (the other shapes: tools/collect_traffic.sh + summarize_traffic.py)
+    sys.path.insert(0, os.getcwd())
+    import __graft_entry__ as ge
+    from summarize_traffic import upsert
+    path = "profiles/hbm_traffic.json"
+    rec = json.load(open(path)) if os.path.exists(path) else {}
+    row = {"dim": 3, "nq": nq, "nelmt": nelmt, "kernel": "hex_wave_kernel", "round": int(rnd),
+           "dispatches": summ["FETCH_SIZE"]["dispatches"], "hbm_read_bytes": round(fetch_b),
+           "hbm_write_bytes": round(write_b), "hbm_bytes_per_launch": round(fetch_b + write_b),
+           "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round((fetch_b + write_b) / alg, 4),
+           "kernel_source_hash": ge.load_package().shard.kernel_source_hash(os.getcwd()),
+           "source": "python3 bench.py under rocprofv3 (tools/collect_profiles.sh)"}
+    upsert(rec, row)
+    rec["round"] = int(rnd)
+    json.dump(rec, open(path, "w"), indent=1)
+    rec = {"rows": [row]}
     ks = [r for r in csv.DictReader(open(f"{dst}/kernel_stats.csv")) if "hex_wave_kernel" in r["Name"]][0]
     print(f"kernel trace: {ks['Calls']} calls, average {float(ks['AverageNs']) * 1e-6:.4f} ms; "
           f"bench.py HIP events in that run {bench['roofline']['kernel_ms']:.4f} ms")
