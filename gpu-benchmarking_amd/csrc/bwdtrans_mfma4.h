@@ -71,10 +71,9 @@ template <int NQ, int EB, int WPB> constexpr size_t mfma4_lds_bytes()
 // GJ: j tiles whose accumulators are live together in step 2 (register budget); KMAP: chunks per wave (chunk_iter,
 // bwdtrans_wave.h; 0 = persistent grid) -- a workgroup pays for its LDS basis copies once, so it should live for
 // several chunks; XG: XCD runs (sf_common.h)
-// STG: waves in odd hardware wave slots start STG*1024 cycles late.  Two waves of a SIMD that start together run the same
-// phases in lock step -- both in their matrix phase (sharing the pipe), then both in their load / store phase (pipe
-// idle) -- and a persistent loop never breaks the symmetry; a one-off stagger of about half a chunk period does.
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, int STG = 0>
+// (Tried and dropped: a persistent grid fed from a device-wide atomic chunk counter, to give it the dispatcher's compact
+// DRAM front -- one address takes ~80 M atomics/s on this part, 6 ms for the 524 288 chunks of a 1 Mi-element batch.)
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
@@ -90,6 +89,22 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     double *slab   = lds + 2 * G::NBAS + wib * G::SLAB;
     const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
     const int e = blk / IB, ib = blk % IB;
+
+    // The wave's first chunk is requested BEFORE the workgroup builds its LDS basis copies: the basis loads, the LDS
+    // writes and the barrier then run underneath the chunk's HBM latency instead of in front of it (a one-chunk wave
+    // otherwise pays for the prologue in full).
+    constexpr uint64_t kNone = ~0ull;
+    const uint64_t nchunk = (nelmt + EB - 1) / EB;
+    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
+    uint64_t c = kNone, cn = kNone; // this chunk, the next one (its loads are requested while this one is computed)
+    if (it.count != 0)
+    {
+        c  = it.first;
+        cn = it.count > 1 ? it.first + it.step : kNone;
+    }
+    typename GW::Vec st[GW::NLD];
+    if (c != kNone)
+        chunk_fetch<GW, EB>(st, in, c, nelmt, lane);
 
     // zero-padded LDS copies of the two bases (once per workgroup); every load is requested before the first is used
     {
@@ -116,27 +131,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
         }
     }
     __syncthreads();
-
-    const uint64_t nchunk = (nelmt + EB - 1) / EB;
-    const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
-    if (it.count == 0)
+    if (c == kNone)
         return;
-    if constexpr (STG > 0)
-    {
-        // HW_ID (hwreg 4) bits 3:0 = wave slot within the SIMD
-        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
-        if (slot & 1)
-        {
-#pragma unroll 1
-            for (int k = 0; k < STG; ++k)
-                __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles
-        }
-    }
-    typename GW::Vec st[GW::NLD];
-    chunk_fetch<GW, EB>(st, in, it.first, nelmt, lane);
 
-    uint64_t c = it.first;
-    for (uint64_t n = 0; n < it.count; ++n, c += it.step)
+    for (uint64_t n = 0;; ++n)
     {
     const uint64_t left = nelmt - c * EB;
     const int evalid    = left >= (uint64_t)EB ? EB : (int)left;
@@ -166,8 +164,12 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             }
     }
     wave_lds_fence();
-    if (n + 1 < it.count)
-        chunk_fetch<GW, EB>(st, in, c + it.step, nelmt, lane);
+    uint64_t cnn = kNone; // the chunk after the next
+    if (cn != kNone)
+    {
+        cnn = n + 2 < it.count ? cn + it.step : kNone;
+        chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
+    }
 
     // ---- step 1: W[q][i] = sum_p In[q][p] B0[p][i]; D = W[q on hi][i on lo] of block (e, ib) ---------------------
     double w[TQ][TG];
@@ -268,8 +270,11 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
     chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
     wave_lds_fence(); // the slab is rewritten by the next chunk's staging
-    if (n + 1 < it.count)
-        touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
+    if (cn == kNone)
+        break;
+    touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
+    c  = cn;
+    cn = cnn;
     }
 }
 

@@ -119,22 +119,24 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
 
 // 4x4x4_4b matrix-core kernel (bwdtrans_mfma4.h), every order 8..32.  Configuration per order from
 // profiles/r02/tune_mfma4_<nq>.log (1 Mi elements, mean of 10 launches, fraction of the 8 TB/s HBM roofline; in brackets
-// the better of the wave kernel and the 16x16x4 kernel on the same box):
-//   21 0.704 (0.697)  22 0.666 (0.625)  23 0.686 (0.612)  24 0.695 (0.583)  25 0.651 (0.593)  26 0.641 (0.570)
-//   27 0.662 (0.575)  28 0.667 (0.602)  29 0.643 (0.595)  30 0.625 (0.583)  31 0.633 (0.611)  32 0.659 (0.696)
-// Up to nq = 24 short-lived workgroups (one chunk per wave) are ahead -- the hardware dispatcher keeps the DRAM front
-// tight, as for the wave kernels; from 25 the per-workgroup prologue (LDS copies of both bases, one barrier) and the
-// unhidden load of a one-chunk wave cost more than that, and a persistent grid with register prefetch wins.
+// the better of the wave kernel and the 16x16x4 kernel in the same run):
+//   21 0.718 (0.698)  22 0.694 (0.635)  23 0.697 (0.615)  24 0.707 (0.583)  25 0.655 (0.584)  26 0.647 (0.567)
+//   27 0.660 (0.577)  28 0.669 (0.605)  29 0.641 (0.578)  30 0.625 (0.587)  31 0.619 (0.613)  32 0.654 (0.702)
+// Up to nq = 24 short-lived workgroups (one or two chunks per wave) are ahead -- the hardware dispatcher keeps the DRAM
+// front tight, as for the wave kernels, and three waves per SIMD fit the LDS; from 25 only two fit, a one-chunk wave can
+// no longer hide its own load, and a persistent grid with register prefetch wins.
 template <int NQ> static int go_mfma4(const QuadArgs &a, hipStream_t s)
 {
     if constexpr (NQ <= 22 || NQ == 24)
         return launch_quad_mfma4<NQ, 2, 4, 2, 4, 1, 64>(a, s); // two elements x two i tiles, one chunk per wave
-    else if constexpr (NQ == 23 || (NQ >= 26 && NQ <= 28))
+    else if constexpr (NQ == 23)
+        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 2, 64>(a, s);
+    else if constexpr (NQ <= 27)
         return launch_quad_mfma4<NQ, 4, 4, 1, 4, 0, 0>(a, s); // four elements per instruction, persistent
-    else if constexpr (NQ == 31 || NQ == 32)
-        return launch_quad_mfma4<NQ, 2, 8, 2, 4, 0, 0>(a, s);
+    else if constexpr (NQ <= 29)
+        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 0, 0>(a, s);
     else
-        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 0, 0>(a, s); // 25, 29, 30
+        return launch_quad_mfma4<NQ, 2, 8, 2, 4, 0, 0>(a, s); // 30, 31, 32
 }
 
 int launch_quad_mfma4_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

@@ -109,11 +109,11 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, int STG = 0>
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0>
 inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, STG>;
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)

@@ -92,15 +92,15 @@ template <class F> static void run(const char *label, const QuadArgs &a, F launc
     std::fflush(stdout);
 }
 
-template <int EB, int WPB, int MW, int GJ, int K, int XG, int STG = 0> static void m4(const QuadArgs &a)
+template <int EB, int WPB, int MW, int GJ, int K, int XG> static void m4(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
     if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
     {
         char label[96];
-        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d stg%d lds %zu", NQ, EB, WPB, MW, GJ, K, XG, STG,
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d lds %zu", NQ, EB, WPB, MW, GJ, K, XG,
                       mfma4_lds_bytes<NQ, EB, WPB>());
-        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, STG>(a, 0); });
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG>(a, 0); });
     }
 }
 
@@ -133,12 +133,12 @@ int main(int argc, char **argv)
         run("shipped wave kernel", a, [&]() { return launch_quad_wave_nq(NQ, a, 0); });
         run("shipped 16x16x4 matrix-core kernel", a, [&]() { return launch_quad_mfma_nq(NQ, a, 0); });
         m4<2, 4, 2, 4, 1, 64>(a);
+        m4<2, 4, 2, 4, 2, 64>(a);
         m4<2, 4, 2, 4, 4, 64>(a);
-        m4<2, 8, 2, 4, 4, 64>(a);
         m4<2, 4, 2, 4, 0, 0>(a);
         m4<2, 8, 2, 4, 0, 0>(a);
         m4<4, 4, 1, 4, 0, 0>(a);
-        m4<4, 2, 1, 4, 4, 64>(a);
+        m4<4, 2, 1, 4, 1, 64>(a);
     }
     return 0;
 }
