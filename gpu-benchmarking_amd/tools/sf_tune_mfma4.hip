@@ -132,13 +132,14 @@ int main(int argc, char **argv)
     {
         run("shipped wave kernel", a, [&]() { return launch_quad_wave_nq(NQ, a, 0); });
         run("shipped 16x16x4 matrix-core kernel", a, [&]() { return launch_quad_mfma_nq(NQ, a, 0); });
-        m4<2, 4, 2, 4, 1, 64>(a);
-        m4<2, 4, 2, 4, 2, 64>(a);
-        m4<2, 4, 2, 4, 4, 64>(a);
         m4<2, 4, 2, 4, 0, 0>(a);
-        m4<2, 8, 2, 4, 0, 0>(a);
         m4<4, 4, 1, 4, 0, 0>(a);
-        m4<4, 2, 1, 4, 1, 64>(a);
+        m4<1, 8, 4, 4, 1, 64>(a);
+        m4<1, 4, 4, 4, 1, 64>(a);
+        m4<1, 8, 3, 4, 1, 64>(a);
+        m4<1, 8, 4, 8, 1, 64>(a);
+        m4<1, 8, 4, 4, 2, 64>(a);
+        m4<1, 16, 4, 4, 1, 64>(a);
     }
     return 0;
 }
