@@ -62,10 +62,11 @@ template <int NQ, int EB> struct Mfma4Geom
     static constexpr int SLAB  = (SLAB0 + 1) & ~1; // doubles per wave
 };
 
-template <int NQ, int EB, int WPB> constexpr size_t mfma4_lds_bytes()
+// SHB: both directions use the SAME basis array (b0 == b1, the isotropic case of every benchmark run): one LDS copy
+template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_bytes()
 {
     using G = Mfma4Geom<NQ, EB>;
-    return sizeof(double) * (size_t)(2 * G::NBAS + WPB * G::SLAB);
+    return sizeof(double) * (size_t)((SHB ? 1 : 2) * G::NBAS + WPB * G::SLAB);
 }
 
 // GJ: j tiles whose accumulators are live together in step 2 (register budget); KMAP: chunks per wave (chunk_iter,
@@ -73,7 +74,7 @@ template <int NQ, int EB, int WPB> constexpr size_t mfma4_lds_bytes()
 // several chunks; XG: XCD runs (sf_common.h)
 // (Tried and dropped: a persistent grid fed from a device-wide atomic chunk counter, to give it the dispatcher's compact
 // DRAM front -- one address takes ~80 M atomics/s on this part, 6 ms for the 524 288 chunks of a 1 Mi-element batch.)
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0>
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt)
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     constexpr int NM = G::NM, IB = G::IB, TQ = G::TQ, TI = G::TI, TG = G::TG, BS = G::BS;
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *bl0 = lds, *bl1 = lds + G::NBAS;
+    double *bl0 = lds, *bl1 = SHB ? lds : lds + G::NBAS;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *slab   = lds + 2 * G::NBAS + wib * G::SLAB;
+    double *slab   = lds + (SHB ? 1 : 2) * G::NBAS + wib * G::SLAB;
     const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
     const int e = blk / IB, ib = blk % IB;
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             const int p = x / BS, i = x - p * BS;
             const bool real = p < NM && i < NQ;
             v0[k] = real ? b0[p * NQ + i] : 0.0;
-            v1[k] = real ? b1[p * NQ + i] : 0.0;
+            v1[k] = (real && !SHB) ? b1[p * NQ + i] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             if (x < G::NBAS)
             {
                 bl0[x] = v0[k];
-                bl1[x] = v1[k];
+                if constexpr (!SHB)
+                    bl1[x] = v1[k];
             }
         }
     }

@@ -109,15 +109,13 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0>
-inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB>
+inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG>;
-    constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB>();
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB>;
+    constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, SHB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
-    if (a.nelmt == 0)
-        return SF_OK;
     const uint64_t nchunk = (a.nelmt + EB - 1) / EB;
     const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
@@ -129,6 +127,20 @@ inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
     kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SF_OK : (int)e;
+}
+
+// SHBOK: the configuration only fits the LDS with one basis copy (b0 == b1); with two different arrays ALT runs instead
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHBONLY = false>
+inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
+{
+    if (a.nelmt == 0)
+        return SF_OK;
+    if (a.b0 == a.b1)
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true>(a, s);
+    if constexpr (SHBONLY)
+        return SF_ENOTBUILT;
+    else
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false>(a, s);
 }
 
 template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>

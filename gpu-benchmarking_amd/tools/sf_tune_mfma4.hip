@@ -95,7 +95,14 @@ template <class F> static void run(const char *label, const QuadArgs &a, F launc
 template <int EB, int WPB, int MW, int GJ, int K, int XG> static void m4(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
-    if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
+    if constexpr (mfma4_lds_bytes<NQ, EB, WPB, true>() <= 160 * 1024 && mfma4_lds_bytes<NQ, EB, WPB>() > 160 * 1024)
+    {
+        char label[96];
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d shb lds %zu", NQ, EB, WPB, MW, GJ,
+                      K, XG, mfma4_lds_bytes<NQ, EB, WPB, true>());
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, true>(a, 0); });
+    }
+    else if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
     {
         char label[96];
         std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d lds %zu", NQ, EB, WPB, MW, GJ, K, XG,
@@ -120,7 +127,8 @@ int main(int argc, char **argv)
     CK(hipMalloc((void **)&g_ref, sizeof(double) * g_nout));
     tune::capacity() = {sizeof(double) * nelmt * NM * NM, sizeof(double) * g_nout, sizeof(double) * NM * NQ};
     fill_random(b0, NM * NQ, 11, 0, 0);
-    fill_random(b1, NM * NQ, 12, 0, 0);
+    CK(hipFree(b1));
+    b1 = b0; // the isotropic case of every benchmark run: both directions share one basis array
     fill_random(in, nelmt * NM * NM, 0x5F3759DF, 0, 0);
     CK(hipDeviceSynchronize());
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
@@ -132,14 +140,14 @@ int main(int argc, char **argv)
     {
         run("shipped wave kernel", a, [&]() { return launch_quad_wave_nq(NQ, a, 0); });
         run("shipped 16x16x4 matrix-core kernel", a, [&]() { return launch_quad_mfma_nq(NQ, a, 0); });
+        m4<2, 4, 2, 4, 1, 64>(a);
+        m4<2, 4, 2, 4, 2, 64>(a);
+        m4<2, 4, 2, 4, 4, 64>(a);
         m4<2, 4, 2, 4, 0, 0>(a);
+        m4<2, 8, 2, 4, 0, 0>(a);
         m4<4, 4, 1, 4, 0, 0>(a);
-        m4<1, 8, 4, 4, 1, 64>(a);
-        m4<1, 4, 4, 4, 1, 64>(a);
-        m4<1, 8, 3, 4, 1, 64>(a);
-        m4<1, 8, 4, 8, 1, 64>(a);
-        m4<1, 8, 4, 4, 2, 64>(a);
-        m4<1, 16, 4, 4, 1, 64>(a);
+        m4<4, 2, 1, 4, 1, 64>(a);
+        m4<2, 3, 3, 4, 1, 64>(a);
     }
     return 0;
 }
