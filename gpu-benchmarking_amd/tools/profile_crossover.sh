@@ -40,4 +40,8 @@ done
 for nq in 12 16 20 24 28 32; do
   run quad_nq${nq}_mfma "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant mfma || exit 1
 done
+# round 2: the 4x4x4_4b matrix-core kernel (AUTO at nq 21..31)
+for nq in 16 20 22 24 26 28 30 32; do
+  run quad_nq${nq}_mfma4 "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant mfma4 || exit 1
+done
 echo all-done
