@@ -388,6 +388,8 @@ def extras(sf, torch, dev, shard, nelmt=1 << 20, reps=40):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                fn()                           # first use on THIS stream (the library's per-stream scratch is
+                side.synchronize()             # allocated on first use, which a capture does not allow)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
                     for _ in range(inner):

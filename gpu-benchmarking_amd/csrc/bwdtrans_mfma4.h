@@ -72,12 +72,14 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // GJ: j tiles whose accumulators are live together in step 2 (register budget); KMAP: chunks per wave (chunk_iter,
 // bwdtrans_wave.h; 0 = persistent grid) -- a workgroup pays for its LDS basis copies once, so it should live for
 // several chunks; XG: XCD runs (sf_common.h)
-// (Tried and dropped: a persistent grid fed from a device-wide atomic chunk counter, to give it the dispatcher's compact
-// DRAM front -- one address takes ~80 M atomics/s on this part, 6 ms for the 524 288 chunks of a 1 Mi-element batch.)
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false>
+// DYNB > 0: a persistent grid whose waves take BATCHES of DYNB consecutive chunks from a device-wide counter
+// (`next_batch`, zeroed before the launch) instead of a fixed share: a fixed share makes the launch as slow as its
+// slowest wave, and waves do not run at equal speed (their CU's neighbours, their XCD's memory channels).  One
+// address takes ~80 M atomics/s on this part, hence batches; the counter is read a whole batch ahead.
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
-    double *__restrict__ out, uint64_t nelmt)
+    double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr)
 {
     using G  = Mfma4Geom<NQ, EB>;
     using GW = WaveGeom<NQ, EB, 2>; // chunk_load / chunk_flush geometry (IN_DBL, NLD, OUT_DBL)
@@ -98,7 +100,28 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const uint64_t nchunk = (nelmt + EB - 1) / EB;
     const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
     uint64_t c = kNone, cn = kNone; // this chunk, the next one (its loads are requested while this one is computed)
-    if (it.count != 0)
+    // batch counter: issue (lane 0) now, look at the value a batch later
+    auto grab_issue = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0)
+            v = __hip_atomic_fetch_add(next_batch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto grab_finish = [&](unsigned long long v) -> uint64_t { // first chunk of that batch, or kNone
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        const uint64_t first = (((uint64_t)hi32 << 32) | lo32) * (uint64_t)(DYNB > 0 ? DYNB : 1);
+        return first < nchunk ? first : kNone;
+    };
+    unsigned long long pending = 0;
+    if constexpr (DYNB > 0)
+    {
+        c       = grab_finish(grab_issue());
+        pending = grab_issue();
+        if (c != kNone)
+            cn = (DYNB > 1 && c + 1 < nchunk) ? c + 1 : kNone; // kNone here = "ask the counter" (resolved in the loop)
+    }
+    else if (it.count != 0)
     {
         c  = it.first;
         cn = it.count > 1 ? it.first + it.step : kNone;
@@ -167,7 +190,22 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     }
     wave_lds_fence();
     uint64_t cnn = kNone; // the chunk after the next
-    if (cn != kNone)
+    if constexpr (DYNB > 0)
+    {
+        // c was the last chunk of its batch (or of the batch's valid part): the next chunk opens the batch requested
+        // one batch ago
+        if (cn == kNone && ((c + 1) % DYNB == 0 || c + 1 >= nchunk))
+        {
+            cn      = grab_finish(pending);
+            pending = grab_issue();
+        }
+        if (cn != kNone)
+        {
+            chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
+            cnn = ((cn + 1) % DYNB != 0 && cn + 1 < nchunk) ? cn + 1 : kNone;
+        }
+    }
+    else if (cn != kNone)
     {
         cnn = n + 2 < it.count ? cn + it.step : kNone;
         chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);

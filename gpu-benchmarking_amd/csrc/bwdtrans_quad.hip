@@ -122,9 +122,11 @@ int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s)
 // the better of the wave kernel and the 16x16x4 kernel in the same run):
 //   21 0.718 (0.698)  22 0.694 (0.635)  23 0.697 (0.615)  24 0.707 (0.583)  25 0.655 (0.584)  26 0.647 (0.567)
 //   27 0.660 (0.577)  28 0.669 (0.605)  29 0.641 (0.578)  30 0.625 (0.587)  31 0.619 (0.613)  32 0.654 (0.702)
-// Up to nq = 24 short-lived workgroups (one or two chunks per wave) are ahead -- the hardware dispatcher keeps the DRAM
-// front tight, as for the wave kernels, and three waves per SIMD fit the LDS; from 25 only two fit, a one-chunk wave can
-// no longer hide its own load, and a persistent grid with register prefetch wins.
+// Up to nq = 24 short-lived workgroups (one or two chunks per wave) are ahead -- the hardware dispatcher balances them
+// and three waves per SIMD fit the LDS; from 25 only two fit, a one-chunk wave can no longer hide its matrix phase
+// (halving the products lifts it from 0.56 to 0.77 at nq = 28), and a persistent grid with register
+// prefetch wins -- fed in batches from a device-wide counter, +2-5 % over fixed shares
+// (profiles/r02/tune_mfma4_28_dynamic_batches.log).
 template <int NQ> static int go_mfma4(const QuadArgs &a, hipStream_t s)
 {
     if constexpr (NQ <= 22 || NQ == 24)
@@ -132,11 +134,11 @@ template <int NQ> static int go_mfma4(const QuadArgs &a, hipStream_t s)
     else if constexpr (NQ == 23)
         return launch_quad_mfma4<NQ, 2, 4, 2, 4, 2, 64>(a, s);
     else if constexpr (NQ <= 27)
-        return launch_quad_mfma4<NQ, 4, 4, 1, 4, 0, 0>(a, s); // four elements per instruction, persistent
-    else if constexpr (NQ <= 29)
-        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 0, 0>(a, s);
+        // four elements per instruction, persistent grid taking batches of 8 chunks from a device-wide counter
+        // (a fixed share per wave is 2-5 % slower: the launch then waits for its slowest wave)
+        return launch_quad_mfma4<NQ, 4, 4, 1, 4, 0, 0, false, 8>(a, s);
     else
-        return launch_quad_mfma4<NQ, 2, 8, 2, 4, 0, 0>(a, s); // 30, 31, 32
+        return launch_quad_mfma4<NQ, 2, 4, 2, 4, 0, 0, false, 4>(a, s); // 28 .. 32: two elements, batches of 4
 }
 
 int launch_quad_mfma4_nq(unsigned nq, const QuadArgs &a, hipStream_t s)

@@ -5,6 +5,8 @@
 #include "bwdtrans_mfma4.h"
 #include "bwdtrans_wave.h"
 
+#include <mutex>
+
 namespace sf
 {
 
@@ -109,13 +111,17 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB>
+int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out); // aux_kernels.hip (sf_dispatch.h)
+std::recursive_mutex &scratch_mutex();
+
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB>
 inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 {
     static int cache[kMaxDev] = {};
-    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB>;
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, SHB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    static_assert(DYNB == 0 || KMAP == 0, "the batch counter feeds a persistent grid");
     const uint64_t nchunk = (a.nelmt + EB - 1) / EB;
     const uint64_t per    = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
     const uint64_t need   = (nchunk + per - 1) / per;
@@ -124,23 +130,41 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         grid = need;
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
-    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SF_OK : (int)e;
+    if constexpr (DYNB > 0)
+    {
+        // the counter lives in the library's per-stream scratch (kind 2); zeroing and launch are one enqueue unit
+        std::lock_guard<std::recursive_mutex> lock(scratch_mutex());
+        void *p = nullptr;
+        int rc  = scratch_acquire(s, 2, 256, &p);
+        if (rc != SF_OK)
+            return rc;
+        hipError_t e = hipMemsetAsync(p, 0, 8, s);
+        if (e != hipSuccess)
+            return (int)e;
+        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, (unsigned long long *)p);
+        e = hipGetLastError();
+        return e == hipSuccess ? SF_OK : (int)e;
+    }
+    else
+    {
+        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, nullptr);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SF_OK : (int)e;
+    }
 }
 
-// SHBOK: the configuration only fits the LDS with one basis copy (b0 == b1); with two different arrays ALT runs instead
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHBONLY = false>
+// SHBONLY: the configuration only fits the LDS with one basis copy (b0 == b1)
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHBONLY = false, int DYNB = 0>
 inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
 {
     if (a.nelmt == 0)
         return SF_OK;
     if (a.b0 == a.b1)
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true, DYNB>(a, s);
     if constexpr (SHBONLY)
         return SF_ENOTBUILT;
     else
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB>(a, s);
 }
 
 template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
