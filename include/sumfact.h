@@ -17,7 +17,12 @@
  *   - element counts are size_t (the reference's 32-bit `unsigned` overflows at
  *     nelmt*nq^3 > 2^32, i.e. above 8 388 608 elements at nq = 8);
  *   - return value: 0 on success, a positive hipError_t, or a negative SF_E* code.  The reference
- *     reports no errors at all; nothing here aborts the process.
+ *     reports no errors at all; nothing here aborts the process;
+ *   - thread / stream safety: every entry point may be called concurrently from several host threads and on several
+ *     streams of a device.  The library's only internal device memory (reduction partials of sf_sumsq_*, the
+ *     intermediates of the any-extent fallback, the chunk counter of the persistent 2D kernels) is a scratch buffer
+ *     per (device, stream), allocated on the first call that needs it on that stream: that FIRST call may not be
+ *     inside a stream capture; later calls are capture-safe (kernel launches and memset nodes only).
  */
 #ifndef SUMFACT_H
 #define SUMFACT_H
