@@ -20,7 +20,8 @@
 // neighbouring i tiles (EB = 4: four elements, no tile slot is ever idle; EB = 2: two elements x two i tiles, half
 // the LDS footprint per wave; EB = 1: one element x four i tiles).  Operands that are the same for several blocks
 // (the In tile across i tiles, the basis tiles across elements) are LDS reads of one address by several lanes, which
-// the LDS broadcasts; the basis row stride keeps the basis gathers conflict free.  Padding rows / columns (p, q >= nm; i, j >= nq) meet zero
+// the LDS broadcasts; the basis row stride keeps the basis gathers conflict free.
+// Padding rows / columns (p, q >= nm; i, j >= nq) meet zero
 // entries of the LDS basis copies; data indices are clamped into the element, so padding lanes read finite values.
 // The chunk's output is assembled in the slab (the input image is dead after step 1) and leaves as one flat
 // line-aligned 16-byte-per-lane stream (chunk_flush, bwdtrans_wave.h).
@@ -161,160 +162,160 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
 
     for (uint64_t n = 0;; ++n)
     {
-    const uint64_t left = nelmt - c * EB;
-    const int evalid    = left >= (uint64_t)EB ? EB : (int)left;
+        const uint64_t left = nelmt - c * EB;
+        const int evalid    = left >= (uint64_t)EB ? EB : (int)left;
 
-    // ---- chunk: staging registers -> LDS image (HBM layout: flat copy); then request the next chunk -----------------
-    if constexpr (GW::VEC2)
-    {
-#pragma unroll
-        for (int k = 0; k < GW::NLD; ++k)
+        // ---- chunk: staging registers -> LDS image (HBM layout: flat copy); then request the next chunk -----------------
+        if constexpr (GW::VEC2)
         {
-            const int v = k * kWave + lane;
-            if ((k + 1) * kWave <= GW::IN_DBL / 2 || v < GW::IN_DBL / 2)
-                *reinterpret_cast<double2_t *>(slab + 2 * v) = st[k];
-        }
-    }
-    else
-    {
-        const int sh = line_offset<double>(in + c * GW::IN_DBL);
 #pragma unroll
-        for (int k = 0; k < word_grid_regs<GW::IN_DBL, double>(); ++k)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < GW::NLD; ++k)
             {
-                const int f = 2 * (k * kWave + lane) - sh + h;
-                if (f >= 0 && f < GW::IN_DBL)
-                    slab[f] = st[k][h];
+                const int v = k * kWave + lane;
+                if ((k + 1) * kWave <= GW::IN_DBL / 2 || v < GW::IN_DBL / 2)
+                    *reinterpret_cast<double2_t *>(slab + 2 * v) = st[k];
             }
-    }
-    wave_lds_fence();
-    uint64_t cnn = kNone; // the chunk after the next
-    if constexpr (DYNB > 0)
-    {
-        // c was the last chunk of its batch (or of the batch's valid part): the next chunk opens the batch requested
-        // one batch ago
-        if (cn == kNone && ((c + 1) % DYNB == 0 || c + 1 >= nchunk))
-        {
-            cn      = grab_finish(pending);
-            pending = grab_issue();
         }
-        if (cn != kNone)
+        else
         {
+            const int sh = line_offset<double>(in + c * GW::IN_DBL);
+#pragma unroll
+            for (int k = 0; k < word_grid_regs<GW::IN_DBL, double>(); ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    const int f = 2 * (k * kWave + lane) - sh + h;
+                    if (f >= 0 && f < GW::IN_DBL)
+                        slab[f] = st[k][h];
+                }
+        }
+        wave_lds_fence();
+        uint64_t cnn = kNone; // the chunk after the next
+        if constexpr (DYNB > 0)
+        {
+            // c was the last chunk of its batch (or of the batch's valid part): the next chunk opens the batch requested
+            // one batch ago
+            if (cn == kNone && ((c + 1) % DYNB == 0 || c + 1 >= nchunk))
+            {
+                cn      = grab_finish(pending);
+                pending = grab_issue();
+            }
+            if (cn != kNone)
+            {
+                chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
+                cnn = ((cn + 1) % DYNB != 0 && cn + 1 < nchunk) ? cn + 1 : kNone;
+            }
+        }
+        else if (cn != kNone)
+        {
+            cnn = n + 2 < it.count ? cn + it.step : kNone;
             chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
-            cnn = ((cn + 1) % DYNB != 0 && cn + 1 < nchunk) ? cn + 1 : kNone;
         }
-    }
-    else if (cn != kNone)
-    {
-        cnn = n + 2 < it.count ? cn + it.step : kNone;
-        chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
-    }
 
-    // ---- step 1: W[q][i] = sum_p In[q][p] B0[p][i]; D = W[q on hi][i on lo] of block (e, ib) ---------------------
-    double w[TQ][TG];
-#pragma unroll
-    for (int tq = 0; tq < TQ; ++tq)
-#pragma unroll
-        for (int ig = 0; ig < TG; ++ig)
-            w[tq][ig] = 0.0;
-    {
-        int arow[TQ];
+        // ---- step 1: W[q][i] = sum_p In[q][p] B0[p][i]; D = W[q on hi][i on lo] of block (e, ib) ---------------------
+        double w[TQ][TG];
 #pragma unroll
         for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+            for (int ig = 0; ig < TG; ++ig)
+                w[tq][ig] = 0.0;
         {
-            const int q = 4 * tq + lo;
-            arow[tq]    = e * G::ESTR + (q < NM ? q : NM - 1) * G::S;
-        }
-        const double *btile = bl0 + hi * BS + 4 * ib + lo;
-        // operands of p step tp+1 are requested before the products of step tp are issued: an LDS read takes longer
-        // than the few 16-cycle products that consume it, and hipcc does not move it up by itself
-        double a1[2][TQ], bt[2][TG];
-        auto request = [&](int buf, int tp) {
-            const int p  = 4 * tp + hi;
-            const int pc = p < NM ? p : NM - 1;
+            int arow[TQ];
 #pragma unroll
             for (int tq = 0; tq < TQ; ++tq)
-                a1[buf][tq] = slab[arow[tq] + pc];
-#pragma unroll
-            for (int ig = 0; ig < TG; ++ig)
-                bt[buf][ig] = btile[4 * tp * BS + 4 * IB * ig];
-        };
-        request(0, 0);
-#pragma unroll
-        for (int tp = 0; tp < TQ; ++tp)
-        {
-            if (tp + 1 < TQ)
-                request((tp + 1) & 1, tp + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ig = 0; ig < TG; ++ig)
+            {
+                const int q = 4 * tq + lo;
+                arow[tq]    = e * G::ESTR + (q < NM ? q : NM - 1) * G::S;
+            }
+            const double *btile = bl0 + hi * BS + 4 * ib + lo;
+            // operands of p step tp+1 are requested before the products of step tp are issued: an LDS read takes longer
+            // than the few 16-cycle products that consume it, and hipcc does not move it up by itself
+            double a1[2][TQ], bt[2][TG];
+            auto request = [&](int buf, int tp) {
+                const int p  = 4 * tp + hi;
+                const int pc = p < NM ? p : NM - 1;
 #pragma unroll
                 for (int tq = 0; tq < TQ; ++tq)
-                    w[tq][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[tp & 1][tq], bt[tp & 1][ig], w[tq][ig], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
-
-    // ---- step 2: Out[j][i] = sum_q B1[q][j] W[q][i]; D = Out[j on hi][i on lo] ------------------------------------
-    {
-        const double *atile = bl1 + hi * BS + lo;
-        double *oimg        = slab + e * G::NQT + hi * NQ + 4 * ib + lo;
-#pragma unroll
-        for (int j0 = 0; j0 < TI; j0 += GJ)
-        {
-            double o[GJ][TG];
-#pragma unroll
-            for (int t = 0; t < GJ; ++t)
+                    a1[buf][tq] = slab[arow[tq] + pc];
 #pragma unroll
                 for (int ig = 0; ig < TG; ++ig)
-                    o[t][ig] = 0.0;
-            double a2[2][GJ];
-            auto request = [&](int buf, int tq) {
-#pragma unroll
-                for (int t = 0; t < GJ; ++t)
-                    if (j0 + t < TI)
-                        a2[buf][t] = atile[4 * tq * BS + 4 * (j0 + t)];
+                    bt[buf][ig] = btile[4 * tp * BS + 4 * IB * ig];
             };
             request(0, 0);
 #pragma unroll
-            for (int tq = 0; tq < TQ; ++tq)
+            for (int tp = 0; tp < TQ; ++tp)
             {
-                if (tq + 1 < TQ)
-                    request((tq + 1) & 1, tq + 1);
+                if (tp + 1 < TQ)
+                    request((tp + 1) & 1, tp + 1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < GJ; ++t)
-                {
-                    if (j0 + t >= TI)
-                        continue;
-#pragma unroll
-                    for (int ig = 0; ig < TG; ++ig)
-                        o[t][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[tq & 1][t], w[tq][ig], o[t][ig], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int t = 0; t < GJ; ++t)
 #pragma unroll
                 for (int ig = 0; ig < TG; ++ig)
-                {
-                    const int tj = j0 + t;
-                    if (tj < TI && 4 * tj + hi < NQ && 4 * (IB * ig + ib) + lo < NQ)
-                        oimg[4 * tj * NQ + 4 * IB * ig] = o[t][ig];
-                }
+#pragma unroll
+                    for (int tq = 0; tq < TQ; ++tq)
+                        w[tq][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[tp & 1][tq], bt[tp & 1][ig], w[tq][ig], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    }
-    wave_lds_fence();
-    // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
-    chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
-    wave_lds_fence(); // the slab is rewritten by the next chunk's staging
-    if (cn == kNone)
-        break;
-    touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
-    c  = cn;
-    cn = cnn;
+        wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
+
+        // ---- step 2: Out[j][i] = sum_q B1[q][j] W[q][i]; D = Out[j on hi][i on lo] ------------------------------------
+        {
+            const double *atile = bl1 + hi * BS + lo;
+            double *oimg        = slab + e * G::NQT + hi * NQ + 4 * ib + lo;
+#pragma unroll
+            for (int j0 = 0; j0 < TI; j0 += GJ)
+            {
+                double o[GJ][TG];
+#pragma unroll
+                for (int t = 0; t < GJ; ++t)
+#pragma unroll
+                    for (int ig = 0; ig < TG; ++ig)
+                        o[t][ig] = 0.0;
+                double a2[2][GJ];
+                auto request = [&](int buf, int tq) {
+#pragma unroll
+                    for (int t = 0; t < GJ; ++t)
+                        if (j0 + t < TI)
+                            a2[buf][t] = atile[4 * tq * BS + 4 * (j0 + t)];
+                };
+                request(0, 0);
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+                {
+                    if (tq + 1 < TQ)
+                        request((tq + 1) & 1, tq + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < GJ; ++t)
+                    {
+                        if (j0 + t >= TI)
+                            continue;
+#pragma unroll
+                        for (int ig = 0; ig < TG; ++ig)
+                            o[t][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[tq & 1][t], w[tq][ig], o[t][ig], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < GJ; ++t)
+#pragma unroll
+                    for (int ig = 0; ig < TG; ++ig)
+                    {
+                        const int tj = j0 + t;
+                        if (tj < TI && 4 * tj + hi < NQ && 4 * (IB * ig + ib) + lo < NQ)
+                            oimg[4 * tj * NQ + 4 * IB * ig] = o[t][ig];
+                    }
+            }
+        }
+        wave_lds_fence();
+        // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
+        chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
+        wave_lds_fence(); // the slab is rewritten by the next chunk's staging
+        if (cn == kNone)
+            break;
+        touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
+        c  = cn;
+        cn = cnn;
     }
 }
 

@@ -39,13 +39,17 @@ KERNEL_SOURCES = ("bwdtrans_wave.h", "wave_table.h", "bwdtrans_hex.hip", "bwdtra
 
 
 def kernel_source_hash(root):
-    """sha256 (16 hex digits) over the kernel sources a PMC record describes; a record whose hash differs
-    from the tree's was taken on other code and is reported as stale."""
+    """sha256 (16 hex digits) over the CODE of the kernel sources a PMC record describes (comments and white space
+    do not count); a record whose hash differs from the tree's was taken on other code and is reported as stale."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(root, "gpu-benchmarking_amd", "csrc", name), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(root, "gpu-benchmarking_amd", "csrc", name), "r") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 
