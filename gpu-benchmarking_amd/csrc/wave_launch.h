@@ -4,8 +4,7 @@
 #include "bwdtrans_mfma.h"
 #include "bwdtrans_mfma4.h"
 #include "bwdtrans_wave.h"
-
-#include <mutex>
+#include "sf_dispatch.h" // scratch_acquire / scratch_mutex (chunk counter of the persistent 2D kernels)
 
 namespace sf
 {
@@ -110,9 +109,6 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SF_OK : (int)e;
 }
-
-int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out); // aux_kernels.hip (sf_dispatch.h)
-std::recursive_mutex &scratch_mutex();
 
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB>
 inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
