@@ -424,41 +424,42 @@ int oracle_bwdtrans_hex_vector(unsigned nq0, unsigned nq1, unsigned nq2, size_t 
 
 /*
  * Register-blocked form of the same three sweeps for isotropic nq = 2..10 -- the timed CPU baseline
- * (bench.py cpu_baseline, kind "port").  The i direction is held in 4-wide vectors (AVX2 ymm under
- * -mavx2; rows padded to NQP = 4*ceil(nq/4) against zero basis columns), four (r,q) pencils / four j /
- * four k share every basis or intermediate vector they load, and all extents are compile-time constants,
+ * (bench.py cpu_baseline, kind "port").  The i direction is held in ORACLE_VW-wide vectors (4: AVX2 ymm,
+ * 8: AVX-512 zmm; rows padded to a multiple of the width against zero basis columns), 4 / 8 (r,q) pencils, j or
+ * k share every basis or intermediate vector they load, and all extents are compile-time constants,
  * so the loops unroll into straight FMA chains.  Every output is still the ascending-p / ascending-q /
  * ascending-r sum starting from 0.0 of benchmark05.cc:361-423: without FMA contraction (liboracle.so)
  * the result is bit-identical to oracle_bwdtrans_hex_sweeps (tests/test_oracle_golden.py).
  */
-typedef double v4d __attribute__((vector_size(32), aligned(8)));
+#ifndef ORACLE_VW
+#define ORACLE_VW 4 /* doubles per vector: 4 = AVX2 ymm (liboracle_fast.so), 8 = AVX-512 zmm (liboracle_avx512.so) */
+#endif
+#define HB_VW ORACLE_VW
+#define HB_RB (HB_VW == 8 ? 8 : 4) /* rows / columns that share every vector they load */
+typedef double hbv __attribute__((vector_size(8 * HB_VW), aligned(8)));
 #define HB_MAXQ 10
-#define HB_MAXP 12
-
+#define HB_MAXP 16
 #define HB_INLINE static inline __attribute__((always_inline))
 
 /* dir 0, NB consecutive (r,q) rows: w1[rq][i] = sum_p in[rq][p] * B0[p][i] */
 HB_INLINE void hb_dir0(const int NM, const int NV, const int NB, const double *restrict b0p,
                        const double *restrict src, double *restrict dst)
 {
-    const int NQP = 4 * NV;
-    v4d acc[4][(HB_MAXP / 4)];
+    const int NQP = HB_VW * NV;
+    hbv acc[HB_RB][(HB_MAXP / HB_VW)];
     for (int t = 0; t < NB; ++t)
         for (int v = 0; v < NV; ++v)
-            acc[t][v] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc[t][v] = (hbv){0.0};
     for (int p = 0; p < NM; ++p)
         for (int v = 0; v < NV; ++v)
         {
-            const v4d b = *(const v4d *)(b0p + p * NQP + 4 * v);
+            const hbv b = *(const hbv *)(b0p + p * NQP + HB_VW * v);
             for (int t = 0; t < NB; ++t)
-            {
-                const double u = src[t * NM + p];
-                acc[t][v] += (v4d){u, u, u, u} * b;
-            }
+                acc[t][v] += src[t * NM + p] * b;
         }
     for (int t = 0; t < NB; ++t)
         for (int v = 0; v < NV; ++v)
-            *(v4d *)(dst + t * NQP + 4 * v) = acc[t][v];
+            *(hbv *)(dst + t * NQP + HB_VW * v) = acc[t][v];
 }
 
 /* dirs 1 and 2, NB consecutive output columns c: dst_c[i] = sum_m src[m*SS + i] * B[m*NQ + c]; PADDED: rows of
@@ -467,28 +468,25 @@ HB_INLINE void hb_dir12(const int NM, const int NQ, const int NV, const int NB, 
                         const int PADDED, const double *restrict bas, const double *restrict src,
                         double *restrict dst)
 {
-    v4d acc[4][(HB_MAXP / 4)];
+    hbv acc[HB_RB][(HB_MAXP / HB_VW)];
     for (int t = 0; t < NB; ++t)
         for (int v = 0; v < NV; ++v)
-            acc[t][v] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc[t][v] = (hbv){0.0};
     for (int m = 0; m < NM; ++m)
         for (int v = 0; v < NV; ++v)
         {
-            const v4d s = *(const v4d *)(src + m * SS + 4 * v);
+            const hbv s = *(const hbv *)(src + m * SS + HB_VW * v);
             for (int t = 0; t < NB; ++t)
-            {
-                const double b = bas[m * NQ + t];
-                acc[t][v] += s * (v4d){b, b, b, b};
-            }
+                acc[t][v] += s * bas[m * NQ + t];
         }
     for (int t = 0; t < NB; ++t)
         for (int v = 0; v < NV; ++v)
         {
-            if (PADDED || 4 * v + 4 <= NQ)
-                *(v4d *)(dst + t * DS + 4 * v) = acc[t][v];
+            if (PADDED || HB_VW * v + HB_VW <= NQ)
+                *(hbv *)(dst + t * DS + HB_VW * v) = acc[t][v];
             else
-                for (int x = 0; 4 * v + x < NQ; ++x)
-                    dst[t * DS + 4 * v + x] = acc[t][v][x];
+                for (int x = 0; HB_VW * v + x < NQ; ++x)
+                    dst[t * DS + HB_VW * v + x] = acc[t][v][x];
         }
 }
 
@@ -496,33 +494,33 @@ HB_INLINE void hex_blocked_element(const int NQ, const double *restrict b0p, con
                                    const double *restrict b2, const double *restrict ine,
                                    double *restrict oute)
 {
-    const int NM = NQ - 1, NV = (NQ + 3) / 4, NQP = 4 * NV;
-    double w1[(HB_MAXQ - 1) * (HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(32)));
-    double w2[(HB_MAXQ - 1) * HB_MAXQ * HB_MAXP] __attribute__((aligned(32)));
-    /* dir 0: w1[r][q][i], four (r,q) rows per pass */
+    const int NM = NQ - 1, NV = (NQ + HB_VW - 1) / HB_VW, NQP = HB_VW * NV;
+    double w1[(HB_MAXQ - 1) * (HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(64)));
+    double w2[(HB_MAXQ - 1) * HB_MAXQ * HB_MAXP] __attribute__((aligned(64)));
+    /* dir 0: w1[r][q][i], HB_RB (r,q) rows per pass */
     {
-        const int NR = NM * NM, full = NR / 4 * 4;
-        for (int rq = 0; rq < full; rq += 4)
-            hb_dir0(NM, NV, 4, b0p, ine + rq * NM, w1 + rq * NQP);
+        const int NR = NM * NM, full = NR / HB_RB * HB_RB;
+        for (int rq = 0; rq < full; rq += HB_RB)
+            hb_dir0(NM, NV, HB_RB, b0p, ine + rq * NM, w1 + rq * NQP);
         if (NR - full)
             hb_dir0(NM, NV, NR - full, b0p, ine + full * NM, w1 + full * NQP);
     }
-    /* dir 1: w2[r][j][i] = sum_q w1[r][q][i] * B1[q][j], four j per pass */
+    /* dir 1: w2[r][j][i] = sum_q w1[r][q][i] * B1[q][j], HB_RB j per pass */
     for (int r = 0; r < NM; ++r)
     {
-        const int full = NQ / 4 * 4;
-        for (int j = 0; j < full; j += 4)
-            hb_dir12(NM, NQ, NV, 4, NQP, NQP, 1, b1 + j, w1 + r * NM * NQP, w2 + (r * NQ + j) * NQP);
+        const int full = NQ / HB_RB * HB_RB;
+        for (int j = 0; j < full; j += HB_RB)
+            hb_dir12(NM, NQ, NV, HB_RB, NQP, NQP, 1, b1 + j, w1 + r * NM * NQP, w2 + (r * NQ + j) * NQP);
         if (NQ - full)
             hb_dir12(NM, NQ, NV, NQ - full, NQP, NQP, 1, b1 + full, w1 + r * NM * NQP,
                      w2 + (r * NQ + full) * NQP);
     }
-    /* dir 2: out[k][j][i] = sum_r w2[r][j][i] * B2[r][k], four k per pass */
+    /* dir 2: out[k][j][i] = sum_r w2[r][j][i] * B2[r][k], HB_RB k per pass */
     for (int j = 0; j < NQ; ++j)
     {
-        const int full = NQ / 4 * 4;
-        for (int k = 0; k < full; k += 4)
-            hb_dir12(NM, NQ, NV, 4, NQ * NQP, NQ * NQ, 0, b2 + k, w2 + j * NQP, oute + (k * NQ + j) * NQ);
+        const int full = NQ / HB_RB * HB_RB;
+        for (int k = 0; k < full; k += HB_RB)
+            hb_dir12(NM, NQ, NV, HB_RB, NQ * NQP, NQ * NQ, 0, b2 + k, w2 + j * NQP, oute + (k * NQ + j) * NQ);
         if (NQ - full)
             hb_dir12(NM, NQ, NV, NQ - full, NQ * NQP, NQ * NQ, 0, b2 + full, w2 + j * NQP,
                      oute + (full * NQ + j) * NQ);
@@ -560,8 +558,8 @@ int oracle_bwdtrans_hex_blocked(unsigned nq0, unsigned nq1, unsigned nq2, size_t
 {
     if (!oracle_has_blocked(nq0, nq1, nq2))
         return -1;
-    const unsigned nq = nq0, nm = nq - 1, nqp = (nq + 3) / 4 * 4;
-    double b0p[(HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(32)));
+    const unsigned nq = nq0, nm = nq - 1, nqp = (nq + HB_VW - 1) / HB_VW * HB_VW;
+    double b0p[(HB_MAXQ - 1) * HB_MAXP] __attribute__((aligned(64)));
     for (unsigned p = 0; p < nm; ++p)
         for (unsigned i = 0; i < nqp; ++i)
             b0p[p * nqp + i] = i < nq ? basis0[p * nq + i] : 0.0;

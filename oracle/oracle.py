@@ -19,7 +19,7 @@ _c_dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     """Compile the C restatement (gcc).  Building the checker is not using it."""
-    want = [os.path.join(_BUILD, n) for n in ("liboracle.so", "liboracle_fast.so")]
+    want = [os.path.join(_BUILD, n) for n in ("liboracle.so", "liboracle_fast.so", "liboracle_avx512.so")]
     src = os.path.join(_HERE, "bwdtrans_ref.c")
     if force or not all(os.path.exists(w) and os.path.getmtime(w) >= os.path.getmtime(src)
                         for w in want):
@@ -27,10 +27,27 @@ def build(force=False):
     return want
 
 
+def host_has_avx512():
+    """True when every CPU flag liboracle_avx512.so was compiled for is listed in /proc/cpuinfo."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    return {"avx512f", "avx512vl", "avx512dq", "fma"} <= flags
+    except OSError:
+        pass
+    return False
+
+
 def _lib(fast=False):
-    key = "fast" if fast else "parity"
+    """fast: False = parity build (-O2, no contraction), True = AVX2/FMA build, "avx512" = 8-wide build."""
+    key = "avx512" if fast == "avx512" else "fast" if fast else "parity"
+    if key == "avx512" and not host_has_avx512():
+        raise RuntimeError("liboracle_avx512.so needs avx512f/vl/dq, which this host does not list")
     if key not in _LIBS:
-        path = os.path.join(_BUILD, "liboracle_fast.so" if fast else "liboracle.so")
+        path = os.path.join(_BUILD, {"parity": "liboracle.so", "fast": "liboracle_fast.so",
+                                     "avx512": "liboracle_avx512.so"}[key])
         if not os.path.exists(path):
             build()
         lib = ctypes.CDLL(path)

@@ -145,6 +145,9 @@ def test_blocked_form_is_the_same_sums(oracle):
         assert oracle.has_blocked(nq) and np.array_equal(s, k), nq
         f = oracle.bwdtrans_hex((nq,) * 3, nelmt, *b, x, form="blocked", fast=True)
         assert oracle.rel_err(f, s) < 1e-14
+        if oracle.host_has_avx512():    # the 8-wide build of the same source (bench.py times the faster of the two)
+            w = oracle.bwdtrans_hex((nq,) * 3, nelmt, *b, x, form="blocked", fast="avx512")
+            assert oracle.rel_err(w, s) < 1e-14
     assert not oracle.has_blocked(11)
     with pytest.raises(ValueError):
         oracle.bwdtrans_hex((3, 4, 3), 2, *[oracle.fill_basis(q - 1, q) for q in (3, 4, 3)],
