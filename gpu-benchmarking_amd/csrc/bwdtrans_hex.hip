@@ -67,6 +67,28 @@ template <int NQ> static int go(const HexArgs &a, hipStream_t s)
     constexpr uint64_t per_block = (uint64_t)C::EC * C::WPB * (C::KM > 0 ? C::KM : 1);
     if (a.nelmt < 2 * per_block * (uint64_t)device_info().num_cu)
         return launch_hex_wave<NQ, HexSmall<NQ>::EC, 1, C::BM, C::MW, 1, HexSmall<NQ>::OUT>(a, s);
+    // Very large batches (BASELINE configs[4]: 10 M elements = 68 GB): elements are independent, so the batch is
+    // enqueued as back-to-back launches of hex_piece(NQ) elements each.  Over a launch of many milliseconds the eight
+    // XCDs drift apart and the DRAM access front widens; a launch boundary every ~0.6 ms re-aligns them: +2 % at
+    // nq = 7 / 8 from 2.5 M elements up, nothing at 1 Mi, nothing at nq 9 / 10, a loss at the low orders whose
+    // pieces would be short launches (profiles/r02/large_batch_split.log) -- hence per order.
+    constexpr uint64_t piece = hex_piece(NQ);
+    if (piece > 0 && a.nelmt > 2 * piece)
+    {
+        static_assert(piece == 0 || piece % (8 * 64 * per_block) == 0, "pieces hold whole XCD windows");
+        constexpr uint64_t NMT = (uint64_t)(NQ - 1) * (NQ - 1) * (NQ - 1), NQT = (uint64_t)NQ * NQ * NQ;
+        for (uint64_t lo = 0; lo < a.nelmt; lo += piece)
+        {
+            HexArgs part = a;
+            part.in      = a.in + lo * NMT;
+            part.out     = a.out + lo * NQT;
+            part.nelmt   = a.nelmt - lo < piece ? a.nelmt - lo : piece;
+            const int rc = launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF>(part, s);
+            if (rc != SF_OK)
+                return rc;
+        }
+        return SF_OK;
+    }
     return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF>(a, s);
 }
 

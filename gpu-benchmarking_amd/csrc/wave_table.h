@@ -35,6 +35,12 @@ SF_HEX_CFG(10, 1,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 313 / 309 (two-
 SF_HEX_CFG(11, 1,   4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 314 (matrix-core kernel: 281); 131 072 elements
 #undef SF_HEX_CFG
 
+// elements per launch when a batch is large enough to be enqueued in pieces (bwdtrans_hex.hip, go<NQ>()); 0 = never
+constexpr uint64_t hex_piece(int nq)
+{
+    return (nq == 7 || nq == 8) ? (1ull << 19) : 0;
+}
+
 template <int NQ> struct QuadCfg;
 #define SF_QUAD_CFG(NQ_, EC_, WPB_, BM_, MW_, KM_, OUT_, MF_)                                       \
     template <> struct QuadCfg<NQ_>                                                                \

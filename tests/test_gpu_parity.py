@@ -580,3 +580,25 @@ def test_hex_64bit_indexing(sf, oracle, torch_mod):
     ss = sf.sumsq(out)
     ss1 = sf.sumsq(out[:nq ** 3])
     assert abs(ss - nelmt * ss1) <= 1e-11 * ss
+
+
+@pytest.mark.parametrize("nq", [7, 8])
+def test_large_batches_enqueued_in_pieces(sf, oracle, torch_mod, nq):
+    """From 2 x 524 288 elements up, nq = 7 / 8 batches are enqueued as back-to-back launches of 524 288
+    elements (wave_table.h hex_piece(), bwdtrans_hex.hip): windows across every launch seam and over the short
+    last piece against the oracle, and the whole output bit-identical to the same batch computed in two halves
+    that stay below the threshold."""
+    piece, nm = 1 << 19, nq - 1
+    nelmt = 2 * piece + 4099                       # pieces: 524 288 + 524 288 + 4 099
+    b = [sf.fill_random(nm * nq, 400 + nq + d) for d in range(3)]
+    bh = [_np(v) for v in b]
+    x = sf.fill_random(nelmt * nm ** 3, 6000 + nq)
+    out = sf.bwdtrans_hex((nq,) * 3, *b, x)
+    win = 300
+    for lo in (0, piece - win // 2, 2 * piece - win // 2, nelmt - win):
+        ref = oracle.bwdtrans_hex((nq,) * 3, win, *bh, _np(x[lo * nm ** 3:(lo + win) * nm ** 3]))
+        assert oracle.rel_err(_np(out[lo * nq ** 3:(lo + win) * nq ** 3]), ref) <= TOL, (nq, lo)
+    cut = 600_001                                   # two single launches (each <= 2 pieces), seam elsewhere
+    halves = torch_mod.cat([sf.bwdtrans_hex((nq,) * 3, *b, x[:cut * nm ** 3]),
+                            sf.bwdtrans_hex((nq,) * 3, *b, x[cut * nm ** 3:])])
+    assert torch_mod.equal(out, halves)
