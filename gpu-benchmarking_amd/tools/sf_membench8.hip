@@ -105,6 +105,11 @@ template <int IN_D, int OUT_D> void shape_rows(int lds_one_wave)
     go<IN_D, OUT_D, 1, 4>(lds_one_wave);
     go<IN_D, OUT_D, 1, 8>(lds_one_wave);
     go<IN_D, OUT_D, 1, 4>(lds_one_wave * 2); // half the waves per CU
+    go<IN_D, OUT_D, 1, 4>(10240);            // 16 waves per CU
+    go<IN_D, OUT_D, 1, 4>(13648);            // 12
+    go<IN_D, OUT_D, 1, 4>(20480);            // 8
+    go<IN_D, OUT_D, 2, 2>(10240);            // 16 waves per CU = 8 elements
+    go<IN_D, OUT_D, 2, 2>(6826);             // 24 waves per CU = 12 elements
     go<IN_D, OUT_D, 2, 1>(lds_one_wave / 2);
     go<IN_D, OUT_D, 2, 2>(lds_one_wave / 2);
     go<IN_D, OUT_D, 2, 4>(lds_one_wave / 2);

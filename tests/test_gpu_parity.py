@@ -598,7 +598,7 @@ def test_large_batches_enqueued_in_pieces(sf, oracle, torch_mod, nq):
     for lo in (0, piece - win // 2, 2 * piece - win // 2, nelmt - win):
         ref = oracle.bwdtrans_hex((nq,) * 3, win, *bh, _np(x[lo * nm ** 3:(lo + win) * nm ** 3]))
         assert oracle.rel_err(_np(out[lo * nq ** 3:(lo + win) * nq ** 3]), ref) <= TOL, (nq, lo)
-    cut = 600_001                                   # two single launches (each <= 2 pieces), seam elsewhere
+    cut = 600_002                                   # two single launches (each <= 2 pieces), seam elsewhere
     halves = torch_mod.cat([sf.bwdtrans_hex((nq,) * 3, *b, x[:cut * nm ** 3]),
                             sf.bwdtrans_hex((nq,) * 3, *b, x[cut * nm ** 3:])])
     assert torch_mod.equal(out, halves)
