@@ -310,7 +310,9 @@ def main():
                          "not recorded for this shape (PMC passes are separate rocprofv3 runs, profiles/README.md)",
                          "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
                          "kernel": "sf::hex_wave_kernel", "bytes_per_element": bytes_per_elmt,
-                         "kernel_ms": round(kernel_s * 1e3, 5)},
+                         "kernel_ms": round(kernel_s * 1e3, 5),
+                         # one step = one library call; a batch above 1 Mi elements is enqueued as several dispatches
+                         "dispatches_per_step": shard.hex_dispatches_per_call(nq, int(per_rank[slowest][0]))},
             "checksum_norm": math.sqrt(float(sums[0])),
         }
         if world > 1:

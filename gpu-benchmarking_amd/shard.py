@@ -53,6 +53,16 @@ def kernel_source_hash(root):
     return h.hexdigest()[:16]
 
 
+HEX_PIECE = {7: 1 << 19, 8: 1 << 19}   # csrc/wave_table.h hex_piece(): elements per dispatch of a large fp64 batch
+
+
+def hex_dispatches_per_call(nq, nelmt):
+    """Kernel dispatches one sf_bwdtrans_hex_f64 call enqueues (csrc/bwdtrans_hex.hip go<NQ>(): a batch above two
+    pieces is enqueued piece by piece)."""
+    piece = HEX_PIECE.get(nq, 0)
+    return -(-nelmt // piece) if piece and nelmt > 2 * piece else 1
+
+
 def recorded_traffic(root, dim, nq, nelmt):
     """HBM bytes per launch from the PMC passes committed under profiles/ (None if not recorded for
     this shape).  bench.py cannot collect PMC counters itself (gpurun keeps --pmc runs separate from

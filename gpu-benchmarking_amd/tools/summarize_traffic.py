@@ -55,9 +55,16 @@ def main(root, rnd):
         if not fetch or not write:
             print("no counters for", d)
             continue
-        rd, wr = 2048.0 * sum(fetch) / len(fetch), 1024.0 * sum(write) / len(write)
+        # a batch above 2 x 524 288 elements at 3D nq = 7 / 8 is one library call = several dispatches
+        # (csrc/wave_table.h hex_piece()): bytes per CALL = mean per dispatch x dispatches per call
+        per_call = shard.hex_dispatches_per_call(nq, nelmt) if dim == 3 else 1
+        if len(fetch) % per_call or len(write) % per_call:
+            print("dispatch count of", d, "is not a multiple of", per_call)
+            continue
+        rd, wr = 2048.0 * sum(fetch) / len(fetch) * per_call, 1024.0 * sum(write) / len(write) * per_call
         alg = 8 * nelmt * ((nq - 1) ** dim + nq ** dim)
         row = {"dim": dim, "nq": nq, "nelmt": nelmt, "kernel": kern, "round": int(rnd), "dispatches": len(fetch),
+               "dispatches_per_call": per_call,
                "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 4),
                "read_over_algorithmic": round(rd / (8 * nelmt * (nq - 1) ** dim), 4),

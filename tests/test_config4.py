@@ -170,3 +170,20 @@ def test_bench_spawns_its_own_ranks_config4(sf):
     x = sf.fill_random(TOTAL * NMT, SEED, 0)
     full = math.sqrt(sf.sumsq(sf.bwdtrans_hex((NQ,) * 3, b, b, b, x)))
     assert abs(rec["checksum_norm"] - full) <= 1e-12 * full
+
+
+def test_dispatches_per_call_mirror_the_kernel_table():
+    """shard.hex_dispatches_per_call() (bench.py's `dispatches_per_step`, the PMC summaries) restates
+    csrc/wave_table.h hex_piece(): keep the two in step."""
+    import re
+    import __graft_entry__ as ge
+    shard = ge.load_package().shard
+    text = open(os.path.join(ROOT, "gpu-benchmarking_amd", "csrc", "wave_table.h")).read()
+    m = re.search(r"hex_piece\(int nq\)\s*\{\s*return \(([^)]*)\) \? \(1ull << (\d+)\) : 0;", text)
+    assert m, "hex_piece() changed shape: update shard.HEX_PIECE and this test"
+    orders = sorted(int(x) for x in re.findall(r"nq == (\d+)", m.group(1)))
+    assert shard.HEX_PIECE == {q: 1 << int(m.group(2)) for q in orders}
+    assert shard.hex_dispatches_per_call(8, 1 << 20) == 1            # the headline batch stays one dispatch
+    assert shard.hex_dispatches_per_call(8, 1_250_000) == 3          # config 4: one GPU's shard of the 8-GPU job
+    assert shard.hex_dispatches_per_call(8, 10_000_000) == 20
+    assert shard.hex_dispatches_per_call(10, 10_000_000) == 1
