@@ -52,14 +52,14 @@ template <int NQ> struct QuadCfg;
 //           nq  EC  WPB  basis      MINW KMAP out        GDOF/s min/mean @1Mi (profiles/r01/tune_quad*.log)
 SF_QUAD_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 115 / 112 (9 us kernel: launch-bound)
 SF_QUAD_CFG(3,  42,  4, BASIS_SMEM, 2, 1, OUT_LDS, 8);
-SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 265 / 251
-SF_QUAD_CFG(5,  24,  4, BASIS_SMEM, 2, 1, OUT_LDS, 8);
-SF_QUAD_CFG(6,  10,  4, BASIS_SMEM, 2, 1, OUT_LDS, 0);  // 311 / 304
-SF_QUAD_CFG(7,  18,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);
-SF_QUAD_CFG(8,  8,   4, BASIS_SMEM, 2, 1, OUT_ST16, XG64); // 336 / 331
-SF_QUAD_CFG(9,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 12);
-SF_QUAD_CFG(10, 12,  4, BASIS_SMEM, 1, 1, OUT_LDS, XG64);  // 336 / 329
-SF_QUAD_CFG(11, 10,  4, BASIS_SMEM_COLS, 1, 1, OUT_LDS, XG64 | 12); // 316 (LDS copy of the basis: 297)
+SF_QUAD_CFG(4,  16,  4, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 260 (without XCD runs: 253) -- profiles/r02/tune_quad_low_orders_xcd_runs.log
+SF_QUAD_CFG(5,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 8);  // 294 (24 elements, no XCD runs: 278)
+SF_QUAD_CFG(6,  8,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 319 (ten elements without XCD runs: 305-308)
+SF_QUAD_CFG(7,  6,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64 | 12); // 333 (18 elements: 308)
+SF_QUAD_CFG(8,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 343-346 (eight elements, paired register stores: 315-317)
+SF_QUAD_CFG(9,  4,   4, BASIS_SMEM, 2, 1, OUT_LDS, 8);  // 351 (14 elements: 328; XCD runs: 345-349)
+SF_QUAD_CFG(10, 4,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 349 (twelve elements: 334)
+SF_QUAD_CFG(11, 4,   4, BASIS_SMEM_COLS, 2, 1, OUT_LDS, XG64 | 8); // 353 (ten elements: 311-320; LDS copy of the basis: 297)
 SF_QUAD_CFG(12, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 349 (matrix-core kernel with XCD runs: 344)
 SF_QUAD_CFG(13, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64 | 12); // 355 (341)
 SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 358 (341)
@@ -113,6 +113,32 @@ template <int NQ> struct QuadCfgF32
     static constexpr int EC = 2 * QuadCfg<NQ>::EC, WPB = QuadCfg<NQ>::WPB, BM = QuadCfg<NQ>::BM;
     static constexpr int MW = QuadCfg<NQ>::MW >= 2 ? 4 : 2, KM = 1, OUT = OUT_LDS, MF = quad_f32_mf(NQ);
 };
+
+// fp32, 2D nq = 4 / 6 / 8 / 10: pinned and measured on their own (profiles/r02/tune_quad_low_orders_xcd_runs.log): the fp64
+// rows of these orders moved to four-element chunks under XCD runs; T = float wants eight (the same bytes) -- but not the
+// eight-wave workgroups of the fp64 nq = 10 row, and 32 / 16 elements at nq = 4 / 6
+#define SF_QUAD_F32_LOW(NQ_, EC_, MW_)                                                             \
+    template <> struct QuadCfgF32<NQ_>                                                             \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = 4, BM = BASIS_SMEM, MW = MW_, KM = 1, OUT = OUT_LDS, MF = XG64; \
+    }
+SF_QUAD_F32_LOW(4, 32, 4);  // 465 (without XCD runs: 440)
+SF_QUAD_F32_LOW(6, 16, 4);  // 598-610 (20 elements, no XCD runs: 593-600)
+SF_QUAD_F32_LOW(8, 8, 4);   // 688-691 (16 elements: 662-667)
+SF_QUAD_F32_LOW(10, 8, 4);  // 699-703 (24 elements at two waves per SIMD: 669-671)
+#undef SF_QUAD_F32_LOW
+
+// fp32, 2D nq = 5 / 7 / 9 / 11: likewise pinned (BM_: scalar-operand rows, column blocks at nq = 11)
+#define SF_QUAD_F32_ODD(NQ_, EC_, BM_, MW_, MF_)                                                   \
+    template <> struct QuadCfgF32<NQ_>                                                             \
+    {                                                                                              \
+        static constexpr int EC = EC_, WPB = 4, BM = BM_, MW = MW_, KM = 1, OUT = OUT_LDS, MF = MF_; \
+    }
+SF_QUAD_F32_ODD(5, 16, BASIS_SMEM, 4, XG64 | 8);       // 552 (48 elements, no XCD runs: 503)
+SF_QUAD_F32_ODD(7, 16, BASIS_SMEM, 4, XG64 | 8);       // 628 (36 elements: 596)
+SF_QUAD_F32_ODD(9, 8, BASIS_SMEM, 4, 8);               // 683 (28 elements: 644; with XCD runs: 665)
+SF_QUAD_F32_ODD(11, 8, BASIS_SMEM_COLS, 4, XG64 | 8);  // 686 (20 elements at two waves per SIMD: 656)
+#undef SF_QUAD_F32_ODD
 
 // fp32, 2D nq = 12 .. 16, pinned row by row (not derived from the fp64 rows, which are re-tuned independently): the doubled
 // chunks (16-20 elements) leave 8 waves per CU; four-element chunks measure 721-728 / 727-738 / 727-733 / 770 GDOF/s at

@@ -141,5 +141,40 @@ int main(int argc, char **argv)
         ROW(12, 1024) ROW(13, 1036) ROW(14, 1024) ROW(15, 1036) ROW(16, 1024) ROW(20, 1024) ROW(24, 1024)
 #undef ROW
     }
+    // nq 4 / 6 / 8 / 10: the fp64 rows moved to small chunks under XCD runs (round 2); the same question for T = float
+    for (int rep = 0; rep < 2; ++rep)
+    {
+#define LOW(NQ, EC0, MW0)                                                                          \
+    {                                                                                              \
+        fill_basis_f32(b2, NQ - 1, NQ, 0);                                                         \
+        QuadArgsT<float> qq{b2, b2, in, nullptr, out, nelmt};                                      \
+        quad_case<NQ, EC0, 4, BASIS_SMEM, MW0, 1, OUT_LDS, 0>(qq); /* the pinned row */            \
+        quad_case<NQ, EC0, 4, BASIS_SMEM, MW0, 1, OUT_LDS, 1024>(qq);                              \
+        quad_case<NQ, 16, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(qq);                                 \
+        quad_case<NQ, 8, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(qq);                                  \
+        quad_case<NQ, 8, 8, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(qq);                                  \
+        quad_case<NQ, 4, 4, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(qq);                                  \
+        quad_case<NQ, 4, 8, BASIS_SMEM, 4, 1, OUT_LDS, 1024>(qq);                                  \
+    }
+        LOW(4, 32, 4) LOW(6, 20, 4) LOW(8, 16, 4) LOW(10, 24, 2)
+#undef LOW
+#define ODD(NQ, EC0, BM, MW0, MF0)                                                                 \
+    {                                                                                              \
+        fill_basis_f32(b2, NQ - 1, NQ, 0);                                                         \
+        QuadArgsT<float> qq{b2, b2, in, nullptr, out, nelmt};                                      \
+        quad_case<NQ, EC0, 4, BM, MW0, 1, OUT_LDS, MF0>(qq); /* the pinned row */                  \
+        quad_case<NQ, EC0, 4, BM, MW0, 1, OUT_LDS, 1024 + 8>(qq);                                  \
+        quad_case<NQ, 24, 4, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                     \
+        quad_case<NQ, 16, 4, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                     \
+        quad_case<NQ, 12, 4, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                     \
+        quad_case<NQ, 8, 4, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                      \
+        quad_case<NQ, 8, 4, BM, 4, 1, OUT_LDS, 8>(qq);                                             \
+        quad_case<NQ, 8, 8, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                      \
+        quad_case<NQ, 4, 4, BM, 4, 1, OUT_LDS, 1024 + 8>(qq);                                      \
+    }
+        ODD(5, 48, BASIS_SMEM, 4, 0) ODD(7, 36, BASIS_SMEM, 4, 8) ODD(9, 28, BASIS_SMEM, 4, 8)
+        ODD(11, 20, BASIS_SMEM_COLS, 2, 8)
+#undef ODD
+    }
     return 0;
 }
