@@ -117,13 +117,13 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd + passed, env=env)
 
 
-def time_steps(fn, steps, warmup, torch, dist, world):
+def time_steps(fn, steps, warmup, torch, dist, use_dist):
     """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize.
     Returns (wall seconds of this rank, HIP-event seconds on the launch stream)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -134,7 +134,7 @@ def time_steps(fn, steps, warmup, torch, dist, world):
         fn()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -231,7 +231,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rdev = dev if backend == "nccl" else torch.device("cpu")   # where the reduced scalars live
-    if world > 1:
+    # SF_BENCH_FORCE_DIST=1 (under a launcher): run the collectives even with ONE rank -- exercises the RCCL
+    # communicator, barrier, all-reduces and all-gather on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("SF_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -257,13 +260,13 @@ def main():
     def step():
         sf.bwdtrans_hex((nq,) * 3, b, b, b, x, out=out)
 
-    wall, evs = time_steps(step, args.steps, args.warmup, torch, dist, world)
+    wall, evs = time_steps(step, args.steps, args.warmup, torch, dist, use_dist)
     tmax = torch.tensor([wall, evs], dtype=torch.float64, device=rdev)
     # checksum, rank count and element count all come out of the same SUM all-reduce
     sums = torch.tensor([sf.sumsq(out), 1.0, float(nelmt)], dtype=torch.float64, device=rdev)
     mine = torch.tensor([float(nelmt), evs], dtype=torch.float64, device=rdev)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_gather(per_rank, mine)
@@ -359,8 +362,10 @@ def main():
                 "note": "reference's best variant, 26.389 GDOF/s on an unstated NVIDIA GPU "
                         "(benchmark05/nq8x8x8.log:46); not an MI355X number, so vs_baseline is null"}
     if rank == 0:
+        if use_dist:
+            result["config"]["collectives"] = f"{backend} communicator of {dist.get_world_size()} rank(s)"
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -141,6 +141,31 @@ def test_bench_two_ranks_rehearsal(pkg, tmp_path):
     assert abs(rec["checksum_norm"] - full) <= 1e-12 * full
 
 
+def test_bench_rccl_collectives_with_one_rank(pkg):
+    """The RCCL half of bench.py's N > 1 path on the one GPU of this box: under the launcher with a single rank and
+    SF_BENCH_FORCE_DIST=1 the run builds the nccl (= RCCL) communicator on its device and goes through the barrier,
+    both all-reduces and the all-gather exactly as an N-rank job does (the 2-rank rehearsal above covers the sharding
+    over gloo; RCCL refuses two ranks on one device)."""
+    import sys
+    env = dict(os.environ, SF_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SF_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "5", "--warmup", "1", "--elements-per-gpu", "65536", "--no-extra",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "rccl"
+    assert rec["config"]["collectives"] == "nccl communicator of 1 rank(s)"
+    assert rec["config"]["total_elements"] == 65536 and rec["value"] > 1.0
+    import math
+    x = pkg.fill_random(65536 * 343, 0x5F3759DF, 0)
+    b = pkg.fill_basis(7, 8)
+    full = math.sqrt(pkg.sumsq(pkg.bwdtrans_hex((8, 8, 8), b, b, b, x)))
+    assert abs(rec["checksum_norm"] - full) <= 1e-12 * full
+
+
 def test_anisotropic_cli(pkg, oracle):
     """nq0 != nq1 != nq2 takes the generic path; norm checked against the oracle."""
     import math
