@@ -160,6 +160,33 @@ __global__ __launch_bounds__(kRedThreads) void sumsq_partial_kernel(const double
         part[blockIdx.x] = s;
 }
 
+// Large arrays: a persistent grid of 6 workgroups per CU, thread t takes the 16-byte vectors t, t + T, t + 2T ... with ONE
+// non-temporal load in flight.  A read-only stream behaves unlike the read/write mixes of the BwdTrans kernels: this
+// shape reads at 7.1-7.2 TB/s from 1 GB up (6.8 at 268 MB) where the run-of-tiles shape above reaches 6.4-6.75 and
+// deeper unrolling or larger grids lose 5-20 % (tools/sf_membench9, profiles/r02/membench9_read_only_reduction.log).
+// Shape and order depend on n and the CU count only: deterministic on a given device.
+__global__ __launch_bounds__(kRedThreads) void sumsq_stride_kernel(const double *__restrict__ x, uint64_t n,
+                                                                   double *__restrict__ part)
+{
+    __shared__ double red[kRedThreads / kWave];
+    const uint64_t nv   = n / 2;
+    const double2_t *x2 = reinterpret_cast<const double2_t *>(x);
+    const uint64_t T    = (uint64_t)gridDim.x * kRedThreads;
+    double a0 = 0.0, a1 = 0.0;
+    for (uint64_t v = (uint64_t)blockIdx.x * kRedThreads + threadIdx.x; v < nv; v += T)
+    {
+        const double2_t p = __builtin_nontemporal_load(x2 + v);
+        a0                = __builtin_fma(p.x, p.x, a0);
+        a1                = __builtin_fma(p.y, p.y, a1);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        a0 = __builtin_fma(x[n - 1], x[n - 1], a0);
+    const double s = block_sum(a0 + a1, red);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = s;
+}
+constexpr uint64_t kStrideMinDoubles = 1ull << 24; // 134 MB: below, the run-of-tiles shape is as fast or faster
+
 __global__ __launch_bounds__(kRedThreads) void sumsq_final_kernel(const double *__restrict__ part,
                                                                   int npart,
                                                                   double *__restrict__ result)
@@ -497,7 +524,12 @@ int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s)
     const uint64_t tile  = (uint64_t)kRedThreads * kRedUnroll;
     const uint64_t tiles = (n / 2 + tile - 1) / tile;
     uint64_t blocks;
-    if (((uintptr_t)x & 15u) == 0)
+    if (((uintptr_t)x & 15u) == 0 && n >= kStrideMinDoubles)
+    {
+        blocks = 6ull * (uint64_t)device_info().num_cu;
+        sumsq_stride_kernel<<<(unsigned)blocks, kRedThreads, 0, s>>>(x, n, ws->part);
+    }
+    else if (((uintptr_t)x & 15u) == 0)
     {
         const uint64_t tpb = tiles <= (uint64_t)kRedMaxBlock ? 1 : (tiles + kRedMaxBlock - 1) / kRedMaxBlock;
         if (tpb > 0xffffffffull)
