@@ -12,7 +12,7 @@ out="${1:-$repo/gpurun_out/prof}"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > "$out/kt_bench.json" 2> "$out/kt.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-extra > "$out/kt_bench.json" 2> "$out/kt.err" || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err" || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > "$out/pmc_write.json" 2> "$out/pmc_write.err" || exit 1
 python3 bench.py > "$out/bench_unprofiled.json" 2> "$out/bench_unprofiled.err" || exit 1
