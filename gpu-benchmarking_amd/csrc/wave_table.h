@@ -60,7 +60,7 @@ SF_QUAD_CFG(8,  4,   4, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 343-346 (eight ele
 SF_QUAD_CFG(9,  4,   4, BASIS_SMEM, 2, 1, OUT_LDS, 8);  // 351 (14 elements: 328; XCD runs: 345-349)
 SF_QUAD_CFG(10, 4,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 349 (twelve elements: 334)
 SF_QUAD_CFG(11, 4,   4, BASIS_SMEM_COLS, 2, 1, OUT_LDS, XG64 | 8); // 353 (ten elements: 311-320; LDS copy of the basis: 297)
-SF_QUAD_CFG(12, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 349 (matrix-core kernel with XCD runs: 344)
+SF_QUAD_CFG(12, 3,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 352-355 (four elements: 348; matrix-core kernel with XCD runs: 344)
 SF_QUAD_CFG(13, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64 | 12); // 355 (341)
 SF_QUAD_CFG(14, 4,   4, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64);      // 358 (341)
 SF_QUAD_CFG(15, 4,   8, BASIS_SMEM_COLS16, 2, 1, OUT_LDS, XG64 | 12); // 359 (336)
