@@ -209,6 +209,15 @@ def test_sumsq(sf, oracle, torch_mod):
     # unaligned view (8-byte aligned only)
     x = sf.fill_random(1001, 3)
     assert abs(sf.sumsq(x[1:]) - oracle.sumsq(_np(x)[1:])) <= 1e-13 * 400
+    # from 2^24 values the reduction is a persistent strided grid (aux_kernels.hip, sumsq_stride_kernel): even / odd
+    # counts either side of the switch, an 8-byte-aligned view of a large array (scalar kernel), determinism
+    big = sf.fill_random((1 << 24) + 1025, 21)
+    bh = _np(big)
+    for lo, n in ((0, (1 << 24) - 2), (0, 1 << 24), (0, (1 << 24) + 1), (0, big.numel()), (1, (1 << 24) + 7)):
+        got = sf.sumsq(big[lo:lo + n])
+        ref = oracle.sumsq(bh[lo:lo + n])
+        assert abs(got - ref) <= 1e-13 * ref, (lo, n, got, ref)
+        assert got == sf.sumsq(big[lo:lo + n])
 
 
 def test_vecadd_and_matvec(sf, oracle, golden, torch_mod):
