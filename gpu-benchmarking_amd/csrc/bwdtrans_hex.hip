@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void hex_nq2_stream_kernel(const double *__res
                                                              const double *__restrict__ in,
                                                              double *__restrict__ out, uint64_t nelmt)
 {
-    constexpr int U   = 4; // output pairs per thread
+    // ONE output pair per thread: under bench.py's sweep protocol 0.81-0.82 of the roofline against 0.75-0.77 with four pairs
+    // per thread and 0.72 with sixteen (tools/sf_membench11, profiles/r02/membench11_nq2_stream_shapes.log) -- the shorter a
+    // wave lives between its first and last store, the better this 89 %-writes stream runs
+    constexpr int U   = 1; // output pairs per thread
     const uint64_t nv = nelmt * 4;
     const double c0 = b0[0], c1 = b0[1];
     double2_t *out2 = reinterpret_cast<double2_t *>(out);
@@ -51,7 +54,7 @@ static int launch_hex_nq2(const HexArgs &a, hipStream_t s)
 {
     if (a.nelmt == 0)
         return SF_OK;
-    const uint64_t blocks = (a.nelmt * 4 + 1023) / 1024;
+    const uint64_t blocks = (a.nelmt * 4 + 255) / 256;
     if (blocks > 0x7fffffffull)
         return SF_EINVAL;
     hex_nq2_stream_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
