@@ -24,7 +24,7 @@ template <int NQ> struct HexCfg;
     }
 //          nq  EC  WPB  basis       MINW KMAP out        GDOF/s min/mean @1Mi elements (profiles/r01/tune_hex*.log)
 SF_HEX_CFG(2,  128, 4, BASIS_SMEM, 2, 1, OUT_ST16, 0); //  73 /  70
-SF_HEX_CFG(3,  14,  4, BASIS_SMEM, 2, 1, OUT_LDS, 12);  // 166 / 162
+SF_HEX_CFG(3,  14,  2, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 8);  // 167 (four waves per workgroup, no XCD runs: 162; chunks of 4-8 elements: 158)
 SF_HEX_CFG(4,  4,   8, BASIS_SMEM, 4, 1, OUT_LDS, XG64);  // 237 (EC 8, 4 waves/block: 229)
 SF_HEX_CFG(5,  2,   4, BASIS_SMEM, 2, 1, OUT_LDS, XG64 | 8);  // 267 (profiles/r01/tune_hex5_xcd_runs.log)
 SF_HEX_CFG(6,  2,   8, BASIS_SMEM, 2, 1, OUT_LDS, XG64);  // 284
@@ -96,6 +96,10 @@ template <int NQ> struct HexCfgF32
 };
 // nq = 7, 9: the fp64 rows moved to one element per chunk (their odd nq^3 output then leaves through the 8-byte
 // word-grid store, which is fp64-only); fp32 keeps the two-element-based rule (566 / 585 GDOF/s against 492 / 520)
+template <> struct HexCfgF32<3> // pinned: the fp64 row moved to two-wave workgroups under XCD runs (measured for fp64 only)
+{
+    static constexpr int EC = 28, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = 8;
+};
 template <> struct HexCfgF32<6>
 {
     static constexpr int EC = 4, WPB = 4, BM = BASIS_SMEM, MW = 4, KM = 1, OUT = OUT_LDS, MF = 0; // 552 (8 waves/block: 527)
