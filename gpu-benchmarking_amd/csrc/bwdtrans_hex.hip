@@ -155,8 +155,38 @@ int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
 
 // fp32 (T = float): same kernels with float4 lanes.  Chunks hold twice the fp64 element count (same
 // bytes), always the LDS-staged flat output (the DPP pair store is the fp64 path).
+// nq = 2, T = float: the stream form of hex_nq2_stream_kernel with float4 lanes -- one 16-byte vector per thread holds the
+// four (j, i) outputs of plane k, two threads per element; same multiplication order as the sweeps
+typedef float float4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hex_nq2_stream_f32_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+                                                                 const float *__restrict__ b2, const float *__restrict__ in,
+                                                                 float *__restrict__ out, uint64_t nelmt)
+{
+    const uint64_t nv = nelmt * 2;
+    const uint64_t v  = logical_block<64>() * 256ull + threadIdx.x;
+    if (v < nv)
+    {
+        const float x  = in[v >> 1];
+        const float bk = b2[v & 1];
+        const float x0 = x * b0[0], x1 = x * b0[1];
+        const float4_t r = {(x0 * b1[0]) * bk, (x1 * b1[0]) * bk, (x0 * b1[1]) * bk, (x1 * b1[1]) * bk};
+        __builtin_nontemporal_store(r, reinterpret_cast<float4_t *>(out) + v);
+    }
+}
+
 template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)
 {
+    if constexpr (NQ == 2)
+    {
+        if (a.nelmt == 0)
+            return SF_OK;
+        const uint64_t blocks = (a.nelmt * 2 + 255) / 256;
+        if (blocks > 0x7fffffffull)
+            return SF_EINVAL;
+        hex_nq2_stream_f32_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SF_OK : (int)e;
+    }
     using C = HexCfgF32<NQ>;
     return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
 }

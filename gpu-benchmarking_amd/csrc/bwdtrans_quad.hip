@@ -62,8 +62,35 @@ template <int NQ> static int go(const QuadArgs &a, hipStream_t s)
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF>(a, s);
 }
 
+// nq = 2, T = float: one 16-byte vector per thread = the four outputs of one element
+typedef float float4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void quad_nq2_stream_f32_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+                                                                  const float *__restrict__ in, float *__restrict__ out,
+                                                                  uint64_t nelmt)
+{
+    const uint64_t v = logical_block<64>() * 256ull + threadIdx.x;
+    if (v < nelmt)
+    {
+        const float x  = in[v];
+        const float x0 = x * b0[0], x1 = x * b0[1];
+        const float4_t r = {x0 * b1[0], x1 * b1[0], x0 * b1[1], x1 * b1[1]};
+        __builtin_nontemporal_store(r, reinterpret_cast<float4_t *>(out) + v);
+    }
+}
+
 template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
 {
+    if constexpr (NQ == 2)
+    {
+        if (a.nelmt == 0)
+            return SF_OK;
+        const uint64_t blocks = (a.nelmt + 255) / 256;
+        if (blocks > 0x7fffffffull)
+            return SF_EINVAL;
+        quad_nq2_stream_f32_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SF_OK : (int)e;
+    }
     using C = QuadCfgF32<NQ>;
     return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
 }

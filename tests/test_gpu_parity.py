@@ -387,6 +387,16 @@ def test_fp32_parity(sf, oracle, golden, torch_mod):
             ref = oracle.bwdtrans_quad(nqs, nelmt, *[_np(b).astype(np.float64) for b in bs],
                                        _np(x).astype(np.float64))
             assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nqs, nelmt)
+    # nq = 2 runs dedicated one-vector-per-thread stream kernels (3D, 2D): many XCD windows and a ragged tail
+    for dim, nelmt in ((3, 70001), (2, 140003)):
+        bs = [sf.fill_random(2, 51 + d, dtype=f32) for d in range(dim)]
+        x = sf.fill_random(nelmt, 77, dtype=f32)
+        b64 = [_np(b).astype(np.float64) for b in bs]
+        if dim == 3:
+            out, ref = sf.bwdtrans_hex((2, 2, 2), *bs, x), oracle.bwdtrans_hex((2, 2, 2), nelmt, *b64, _np(x).astype(np.float64))
+        else:
+            out, ref = sf.bwdtrans_quad((2, 2), *bs, x), oracle.bwdtrans_quad((2, 2), nelmt, *b64, _np(x).astype(np.float64))
+        assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (dim, nelmt)
     # fills: the fp64 generator rounded to float; sin/cos in float
     a = _np(sf.fill_random(10007, 5, 3, dtype=f32))
     assert np.array_equal(a, oracle.fill_random(10007, 5, 3).astype(np.float32))
