@@ -12,7 +12,10 @@
 //   matvec / fill_matvec     : benchmark03 (y = A x; benchmark03/benchmark03.cc:15-104, data :160-167)
 #include "sf_dispatch.h"
 
+#include <functional>
 #include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 namespace sf
@@ -402,6 +405,7 @@ struct ScratchSlot
 {
     int dev;
     hipStream_t stream;
+    uint64_t owner; // hipStreamPerThread names a different stream in every host thread: those slots are per thread
     int kind;
     void *ptr;
     size_t bytes;
@@ -423,9 +427,11 @@ int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out)
     if (hipGetDevice(&dev) != hipSuccess)
         return SF_EINVAL;
     std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
+    const uint64_t owner =
+        s == hipStreamPerThread ? (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1u : 0;
     ScratchSlot *slot = nullptr;
     for (auto &c : g_scratch)
-        if (c.dev == dev && c.stream == s && c.kind == kind)
+        if (c.dev == dev && c.stream == s && c.owner == owner && c.kind == kind)
             slot = &c;
     if (!slot)
     {
@@ -441,7 +447,7 @@ int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out)
             (void)hipFree(g_scratch[victim].ptr);
             g_scratch.erase(g_scratch.begin() + (long)victim);
         }
-        g_scratch.push_back(ScratchSlot{dev, s, kind, nullptr, 0, 0});
+        g_scratch.push_back(ScratchSlot{dev, s, owner, kind, nullptr, 0, 0});
         slot = &g_scratch.back();
     }
     if (slot->bytes < bytes)
@@ -462,6 +468,102 @@ int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out)
     slot->tick = ++g_scratch_tick;
     *out       = slot->ptr;
     return SF_OK;
+}
+
+// ---- batch counters of the persistent 2D kernels (sf_dispatch.h: counter_acquire) -----------------------------------
+constexpr unsigned kCounterSlots  = 8192; // per device
+constexpr unsigned kCounterStride = 64;   // bytes: one line per counter
+struct CounterRing
+{
+    char *base    = nullptr;
+    unsigned next = 0;
+    std::vector<std::pair<hipStream_t, unsigned>> eager; // stream -> slot (per-thread streams: one slot per launch)
+};
+static CounterRing g_counters[64];
+static std::mutex g_counter_mu;
+
+int counter_acquire(hipStream_t s, unsigned long long **out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return SF_EINVAL;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_counter_mu);
+    CounterRing &r = g_counters[dev];
+    if (!r.base)
+    {
+        if (capturing) // an allocation would invalidate the capture
+            return SF_ENOMEM;
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)kCounterSlots * kCounterStride) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return SF_ENOMEM;
+        }
+        r.base = static_cast<char *>(p);
+    }
+    unsigned slot = kCounterSlots;
+    if (!capturing && s != hipStreamPerThread)
+        for (auto &e : r.eager)
+            if (e.first == s)
+                slot = e.second;
+    if (slot == kCounterSlots)
+    {
+        if (r.next >= kCounterSlots)
+            return SF_ENOMEM;
+        slot = r.next++;
+        if (!capturing && s != hipStreamPerThread)
+            r.eager.emplace_back(s, slot);
+    }
+    *out = reinterpret_cast<unsigned long long *>(r.base + (size_t)slot * kCounterStride);
+    return SF_OK;
+}
+
+// sf_shutdown(): graphs captured earlier must not be replayed afterwards
+int release_counters()
+{
+    std::lock_guard<std::mutex> lock(g_counter_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && g_counters[dev].base)
+    {
+        (void)hipFree(g_counters[dev].base);
+        g_counters[dev] = CounterRing{};
+    }
+    return SF_OK;
+}
+
+// pinned 8-byte landing slot of the calling host thread: the result of a blocking reduction is copied there
+// asynchronously, so no lock is held while the device works (a copy into pageable memory would block inside the lock)
+struct PinnedSlot
+{
+    double *p = nullptr;
+    ~PinnedSlot()
+    {
+        if (p)
+            (void)hipHostFree(p);
+    }
+};
+static thread_local PinnedSlot t_landing;
+static double *landing_slot()
+{
+    if (!t_landing.p)
+    {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        t_landing.p = static_cast<double *>(p);
+    }
+    return t_landing.p;
 }
 
 struct Workspace
@@ -550,8 +652,12 @@ int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s)
 int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s)
 {
     hipError_t e;
+    double *land = landing_slot();
+    if (!land)
+        return SF_ENOMEM;
     {
-        // kernels + copy are enqueued as one unit; the wait happens outside the lock
+        // kernels + copy are enqueued as one unit; the copy lands in this thread's pinned slot, so it is asynchronous
+        // and the wait happens outside the lock
         std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
         Workspace w, *ws = &w;
         int rc = workspace(s, ws);
@@ -560,16 +666,21 @@ int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s
         rc = sumsq_async(x, n, ws->result, s);
         if (rc != SF_OK)
             return rc;
-        e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+        e = hipMemcpyAsync(land, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        *result_host = *land;
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
 int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_t s)
 {
     hipError_t e;
+    double *land = landing_slot();
+    if (!land)
+        return SF_ENOMEM;
     {
         std::lock_guard<std::recursive_mutex> lock(g_scratch_mu);
         Workspace w, *ws = &w;
@@ -586,10 +697,12 @@ int sumsq_f32_blocking(const float *x, size_t n, double *result_host, hipStream_
         rc = launch_rc();
         if (rc != SF_OK)
             return rc;
-        e = hipMemcpyAsync(result_host, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
+        e = hipMemcpyAsync(land, ws->result, sizeof(double), hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        *result_host = *land;
     return e == hipSuccess ? SF_OK : (int)e;
 }
 

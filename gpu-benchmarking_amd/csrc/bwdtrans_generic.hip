@@ -341,8 +341,21 @@ constexpr size_t kMaxDynLds = 160 * 1024;
 // Launch hints = the reference drivers' `threads` / `elblocks` CLI arguments
 // (benchmark05/benchmark05.cc:1428-1429): block size of the thread-per-element and flat-tid kernels
 // (:1265, :1343) and elements per workgroup of the block-per-element kernels (`blocks = nelmt / elblocks`,
-// :1188).  0 = automatic.  They only shape these reference-style decompositions.
-static unsigned g_hint_threads = 0, g_hint_elblocks = 0;
+// :1188).  0 = automatic.  They only shape these reference-style decompositions.  Per host thread: a thread that sets a
+// hint shapes its own later launches, never another thread's.
+static thread_local unsigned g_hint_threads = 0, g_hint_elblocks = 0;
+
+// The any-extent fallback keeps one intermediate pair per WORKGROUP in the library's scratch; the grid is cut down so that
+// the scratch stays within this budget whatever the order (one workgroup at least).
+constexpr uint64_t kScratchBudgetBytes = 1ull << 30;
+static inline unsigned by_block_grid(uint64_t nelmt, unsigned cu, uint64_t pair_bytes)
+{
+    uint64_t grid = nelmt < (uint64_t)cu * 8 ? nelmt : (uint64_t)cu * 8;
+    const uint64_t fit = pair_bytes ? kScratchBudgetBytes / pair_bytes : grid;
+    if (grid > fit)
+        grid = fit;
+    return (unsigned)(grid < 1 ? 1 : grid);
+}
 
 int set_launch_hint(unsigned threads, unsigned elblocks)
 {
@@ -409,7 +422,9 @@ int launch_hex_generic_t(int variant, unsigned nq0, unsigned nq1, unsigned nq2, 
     if (by_block)
     {
         lock.lock();
-        grid = (unsigned)(a.nelmt < (uint64_t)cu * 8 ? a.nelmt : (uint64_t)cu * 8);
+        if (n1 + n2 > (~(size_t)0) / sizeof(T) / ((size_t)cu * 8))
+            return SF_EINVAL; // the scratch size would overflow
+        grid = by_block_grid(a.nelmt, cu, sizeof(T) * (uint64_t)(n1 + n2));
         void *p = nullptr;
         int rc  = scratch_acquire(s, 1, sizeof(T) * (n1 + n2) * grid, &p);
         if (rc != SF_OK)
@@ -469,7 +484,9 @@ int launch_quad_generic_t(int variant, unsigned nq0, unsigned nq1, const QuadArg
     if (by_block)
     {
         lock.lock();
-        grid = (unsigned)(a.nelmt < (uint64_t)cu * 8 ? a.nelmt : (uint64_t)cu * 8);
+        if (n1 > (~(size_t)0) / sizeof(T) / ((size_t)cu * 8))
+            return SF_EINVAL;
+        grid = by_block_grid(a.nelmt, cu, sizeof(T) * (uint64_t)n1);
         void *p = nullptr;
         int rc  = scratch_acquire(s, 1, sizeof(T) * n1 * grid, &p);
         if (rc != SF_OK)

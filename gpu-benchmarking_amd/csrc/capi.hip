@@ -398,6 +398,7 @@ int sf_device_info(int *num_cu, int *wave_size, char *name, size_t name_len)
 
 int sf_shutdown(void)
 {
+    (void)release_counters();
     return release_workspaces();
 }
 

@@ -35,6 +35,12 @@ int release_workspaces();
 // intermediates.  Hold scratch_mutex() from the acquire to the end of the enqueue sequence that uses the buffer.
 int scratch_acquire(hipStream_t s, int kind, size_t bytes, void **out);
 std::recursive_mutex &scratch_mutex();
+// 8-byte batch counter for one launch of a persistent kernel on `s` (zero it with a memset node in front of the launch).
+// Counters live in one buffer per device that is allocated at first use and freed only by sf_shutdown().  Eager
+// launches on a stream share that stream's counter (their work is ordered); a launch enqueued while `s` is capturing
+// gets a counter of its own (the graph may replay on any stream).  SF_ENOMEM: none to be had -- fall back.
+int counter_acquire(hipStream_t s, unsigned long long **out);
+int release_counters();
 int set_launch_hint(unsigned threads, unsigned elblocks);
 int launch_hex_interleaved(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
 int launch_interleave64(const double *src, double *dst, size_t nelmt, size_t n, int inverse,

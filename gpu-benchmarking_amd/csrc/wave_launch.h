@@ -4,7 +4,9 @@
 #include "bwdtrans_mfma.h"
 #include "bwdtrans_mfma4.h"
 #include "bwdtrans_wave.h"
-#include "sf_dispatch.h" // scratch_acquire / scratch_mutex (chunk counter of the persistent 2D kernels)
+#include "sf_dispatch.h" // counter_acquire (batch counter of the persistent 2D kernels)
+
+#include <atomic>
 
 namespace sf
 {
@@ -12,14 +14,17 @@ namespace sf
 constexpr int kMaxDev = 64;
 
 // Persistent grid: as many workgroups as the device keeps resident (occupancy query, cached per
-// device), never more than there are chunks.
-template <class K> inline int resident_blocks(K kern, int threads, size_t lds, int *cache)
+// device), never more than there are chunks.  The caches are atomics: two host threads that race on the first launch
+// both run the query and store the same answer.
+using OccCache = std::atomic<int>[kMaxDev];
+template <class K> inline int resident_blocks(K kern, int threads, size_t lds, std::atomic<int> *cache)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev)
         dev = 0;
-    if (cache[dev] == 0)
+    int cached = cache[dev].load(std::memory_order_acquire);
+    if (cached == 0)
     {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)kern,
@@ -31,16 +36,17 @@ template <class K> inline int resident_blocks(K kern, int threads, size_t lds, i
             (void)hipGetLastError();
             bpc = 1;
         }
-        cache[dev] = bpc;
+        cache[dev].store(bpc, std::memory_order_release);
+        cached = bpc;
     }
-    return cache[dev] * device_info().num_cu;
+    return cached * device_info().num_cu;
 }
 
 template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM = OUT_ST8, int MEMF = 0,
           typename T = double>
 inline int launch_hex_wave(const HexArgsT<T> &a, hipStream_t s, int grid_override = 0)
 {
-    static int cache[kMaxDev] = {};
+    static OccCache cache = {};
     auto kern            = hex_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF, T>;
     constexpr size_t lds = wave_lds_bytes<NQ, EC, 3, WPB, BMODE, OUTM, T>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
@@ -65,7 +71,7 @@ template <int NQ, int EC, int WPB, int BMODE, int MINW, int KMAP = 0, int OUTM =
           typename T = double>
 inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_override = 0)
 {
-    static int cache[kMaxDev] = {};
+    static OccCache cache = {};
     auto kern            = quad_wave_kernel<NQ, EC, WPB, BMODE, MINW, KMAP, OUTM, MEMF, T>;
     constexpr size_t lds = wave_lds_bytes<NQ, EC, 2, WPB, BMODE, OUTM, T>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
@@ -89,7 +95,7 @@ inline int launch_quad_wave(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
 template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false, int XG = 0>
 inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override = 0)
 {
-    static int cache[kMaxDev] = {};
+    static OccCache cache = {};
     auto kern            = quad_mfma_kernel<NQ, EC, WPB, MINW, KMAP, OUTL, XG>;
     constexpr size_t lds = mfma_lds_bytes<NQ, EC, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
@@ -113,7 +119,7 @@ inline int launch_quad_mfma(const QuadArgs &a, hipStream_t s, int grid_override 
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB>
 inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 {
-    static int cache[kMaxDev] = {};
+    static OccCache cache = {};
     auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, SHB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
@@ -128,16 +134,16 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         return SF_EINVAL;
     if constexpr (DYNB > 0)
     {
-        // the counter lives in the library's per-stream scratch (kind 2); zeroing and launch are one enqueue unit
-        std::lock_guard<std::recursive_mutex> lock(scratch_mutex());
-        void *p = nullptr;
-        int rc  = scratch_acquire(s, 2, 256, &p);
-        if (rc != SF_OK)
-            return rc;
-        hipError_t e = hipMemsetAsync(p, 0, 8, s);
+        // the batch counter comes from the device's counter ring (never evicted: a pointer baked into a captured graph
+        // stays valid until sf_shutdown); no counter to be had (ring exhausted, or first use inside a capture) -> the
+        // same kernel with a fixed share per wave
+        unsigned long long *ctr = nullptr;
+        if (counter_acquire(s, &ctr) != SF_OK)
+            return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0>(a, s);
+        hipError_t e = hipMemsetAsync(ctr, 0, 8, s);
         if (e != hipSuccess)
             return (int)e;
-        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, (unsigned long long *)p);
+        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr);
         e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
     }
@@ -166,7 +172,7 @@ inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
 template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
 inline int launch_hex_mfma(const HexArgs &a, hipStream_t s, int grid_override = 0)
 {
-    static int cache[kMaxDev] = {};
+    static OccCache cache = {};
     auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP, XG>;
     constexpr size_t lds = hex_mfma_lds_bytes<NQ, EC, WPB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");

@@ -224,6 +224,53 @@ template <class F> double time_min(F &&fn, double budget_s = 1e30)
     return best;
 }
 
+// min over n_tests of the DEVICE time of fn() between two HIP events on the stream fn() launches on (a second loop,
+// after time_min's: the reference's wall-clock protocol stays undisturbed).  What the kernels themselves take, without
+// the ~10 us launch + synchronise floor that dominates the wall clock at the low orders; goes to the --json side file.
+template <class F> double event_min(F &&fn, double budget_s = 1e30, hipStream_t stream = nullptr)
+{
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    double best = std::numeric_limits<double>::max(), spent = 0.0;
+    for (unsigned t = 0; t < kTests; ++t)
+    {
+        HIP_CHECK(hipEventRecord(e0, stream));
+        fn();
+        HIP_CHECK(hipEventRecord(e1, stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, 1e-3 * (double)ms);
+        spent += 1e-3 * (double)ms;
+        if (spent > budget_s && t >= 2)
+            break;
+    }
+    HIP_CHECK(hipEventDestroy(e0));
+    HIP_CHECK(hipEventDestroy(e1));
+    return best;
+}
+
+// "[a, b, c]" for the side file; columns that were not run carry 0
+inline std::string json_array(const double *v, int n, double scale = 1.0)
+{
+    std::ostringstream o;
+    o << std::setprecision(10) << "[";
+    for (int i = 0; i < n; ++i)
+        o << (i ? ", " : "") << ((v[i] < 1e300 && v[i] > 0.0) ? scale * v[i] : 0.0);
+    o << "]";
+    return o.str();
+}
+inline std::string json_rate_array(const double *t, int n, double work)
+{
+    std::ostringstream o;
+    o << std::setprecision(10) << "[";
+    for (int i = 0; i < n; ++i)
+        o << (i ? ", " : "") << ((t[i] < 1e300 && t[i] > 0.0) ? work / t[i] : 0.0);
+    o << "]";
+    return o.str();
+}
+
 struct JsonLog
 {
     std::ostringstream body;

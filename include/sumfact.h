@@ -21,10 +21,14 @@
  *   - return value: 0 on success, a positive hipError_t, or a negative SF_E* code.  The reference
  *     reports no errors at all; nothing here aborts the process;
  *   - thread / stream safety: every entry point may be called concurrently from several host threads and on several
- *     streams of a device.  The library's only internal device memory (reduction partials of sf_sumsq_*, the
- *     intermediates of the any-extent fallback, the chunk counter of the persistent 2D kernels) is a scratch buffer
- *     per (device, stream), allocated on the first call that needs it on that stream: that FIRST call may not be
- *     inside a stream capture; later calls are capture-safe (kernel launches and memset nodes only).
+ *     streams of a device (sf_set_launch_hint is per calling thread).  The library's internal device memory:
+ *     (i) reduction partials of sf_sumsq_* and the intermediates of the any-extent fallback (at most 1 GiB, the grid
+ *     is cut down to fit) live in a scratch buffer per (device, stream; per thread for hipStreamPerThread), allocated
+ *     on the first call that needs it on that stream -- that FIRST call may not be inside a stream capture;
+ *     (ii) the batch counters of the persistent 2D kernels (AUTO 2D nq 25..32) live in one 512 KiB buffer per device
+ *     that is allocated once and freed only by sf_shutdown(): BwdTrans launches are capture-safe from the first call
+ *     (kernel and memset nodes only; inside a capture that precedes the buffer's allocation the same kernel runs
+ *     with a fixed share per wave instead), and a captured graph stays replayable until sf_shutdown().
  */
 #ifndef SUMFACT_H
 #define SUMFACT_H
@@ -180,7 +184,8 @@ int sf_fill_matvec_f64(double *A, double *x, unsigned m, unsigned n, void *strea
  * The reference drivers' `threads` / `elblocks` arguments (benchmark05/benchmark05.cc:1428-1429): block
  * size of the thread-per-element / flat-tid kernels and elements per workgroup (`blocks = nelmt/elblocks`,
  * :1188).  They shape only the reference-style decompositions (SF_VARIANT_THREAD / BLOCK_LDS / BLOCK_GLB);
- * the wave and matrix-core kernels choose their own launch shapes.  0 = automatic (default).
+ * the wave and matrix-core kernels choose their own launch shapes.  0 = automatic (default).  The hint belongs to the
+ * CALLING host thread: it shapes that thread's later launches only.
  */
 int sf_set_launch_hint(unsigned threads, unsigned elblocks);
 

@@ -72,6 +72,58 @@ def test_mismatched_launch_exits_nonzero_without_touching_a_gpu():
     assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr and not res.stdout.strip()
 
 
+def _fake_topology(root, simd_counts):
+    for i, simd in enumerate(simd_counts):
+        d = root / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nunique_id {1000 + i}\n")
+    return str(root)
+
+
+def test_gpus_are_counted_from_sysfs_not_from_hip(tmp_path):
+    """The spawning parent counts GPUs from the KFD topology (nodes with simd_count > 0; CPU nodes report 0) and
+    applies the visibility variables itself -- no HIP call, no torch import."""
+    b = _bench()
+    nodes = _fake_topology(tmp_path, [0, 0, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024])
+    assert b.visible_gpu_count({}, nodes) == 8
+    assert b.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,1,2,3"}, nodes) == 4
+    assert b.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "2,5", "HIP_VISIBLE_DEVICES": "0,1,7"}, nodes) == 2
+    assert b.visible_gpu_count({"CUDA_VISIBLE_DEVICES": "1"}, nodes) == 1
+    assert b.visible_gpu_count({"CUDA_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}, nodes) == 2   # HIP_ wins
+    assert b.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,9,1"}, nodes) == 1     # stops at the first bad index
+    assert b.visible_gpu_count({"HIP_VISIBLE_DEVICES": ""}, nodes) == 0
+    assert b.visible_gpu_count({}, str(tmp_path / "absent")) is None               # not a ROCm box: unknown
+
+
+_PARENT_PROBE = """
+import json, sys
+sys.path.insert(0, {root!r})
+import bench
+seen = {{}}
+def fake_call(cmd, env):
+    seen.update(torch_imported='torch' in sys.modules, handles=bench.gpu_handles_open(), cmd=cmd,
+                count=bench.visible_gpu_count())
+    return 0
+rc = bench.spawn_ranks(2, ['--steps', '2'], call=fake_call)
+print(json.dumps(dict(seen, rc=rc)))
+"""
+
+
+def _probe_parent(env):
+    res = subprocess.run([sys.executable, "-c", _PARENT_PROBE.format(root=ROOT)], env=env, capture_output=True,
+                         text=True, timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def test_spawning_parent_stays_clear_of_torch_and_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SF_BENCH_BACKEND"] = "gloo"
+    seen = _probe_parent(env)
+    assert seen["rc"] == 0 and seen["torch_imported"] is False and seen["handles"] == []
+    assert seen["cmd"][1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--gpus" in seen["cmd"]
+
+
 def test_config4_shards_tile_the_batch():
     import __graft_entry__ as ge
     shard = ge.load_package().shard
@@ -150,6 +202,21 @@ def test_bench_refuses_more_ranks_than_gpus(sf):
 
 
 @pytest.mark.gpu
+def test_spawning_parent_holds_no_gpu_device_file(sf):
+    """On the GPU box: at the moment bench.py starts the child launcher the parent has not imported torch, holds
+    neither /dev/kfd nor a /dev/dri node, and its sysfs count equals what the HIP runtime reports to this (other,
+    initialised) process."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SF_BENCH_BACKEND"] = "gloo"
+    seen = _probe_parent(env)
+    assert seen["torch_imported"] is False and seen["handles"] == [], seen
+    assert seen["count"] == torch.cuda.device_count(), seen
+    b = _bench()
+    assert b.gpu_handles_open(), "this test process HAS initialised the GPU: the probe must see its device files"
+
+
+@pytest.mark.gpu
 def test_bench_spawns_its_own_ranks_config4(sf):
     """`python bench.py --gpus 2` with no launcher starts 2 ranks itself (gloo rehearsal: the ranks share this
     box's GPU), defaults to the 10 M-element strong-scaling batch and reports the ranks actually reduced over."""
@@ -165,6 +232,10 @@ def test_bench_spawns_its_own_ranks_config4(sf):
     assert rec["config"]["total_elements"] == TOTAL and rec["config"]["elements_per_gpu"] == TOTAL // 2
     assert len(rec["roofline"]["per_gpu_frac"]) == 2 and "rehearsal" in rec
     assert rec["single_gpu_same_batch_gdof_s"] > 50 and rec["speedup_vs_1gpu_same_batch"] > 0
+    # the N > 1 line is complete: CPU baseline in the same run, traffic of the shard shape, per-GPU fractions
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["cores"] >= 1
+    assert "traffic" in rec["roofline"] and "frac_kernel_events" in rec["roofline"]
+    assert len(rec["roofline"]["per_gpu_wall_ms_per_step"]) == 2
     # checksum of the sharded run == one rank over the whole batch
     b = sf.fill_basis(NM, NQ)
     x = sf.fill_random(TOTAL * NMT, SEED, 0)

@@ -43,6 +43,13 @@ def test_benchmark05_default_cli_sweep(pkg, golden, tmp_path):
             assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
     rec = json.loads(js.read_text())
     assert rec["benchmark"] == "benchmark05" and len(rec["rows"]) == 8
+    # side file: per column the wall-clock minimum the stdout rows are made of AND the HIP-event minimum of the same
+    # launches (kernel level: no launch + synchronise floor), SURVEY s7 step 5
+    for row, values in zip(rec["rows"], log.values):
+        assert len(row["t_wall_min"]) == 6 and len(row["t_event_min"]) == 6 and len(row["gdof_s_event"]) == 6
+        assert all(0 < e <= 1.5 * w for e, w in zip(row["t_event_min"], row["t_wall_min"]))
+        assert abs(row["wave_gdof_s"] - values[3]) <= 1e-6 * values[3]
+        assert row["wave_gdof_s_event"] >= 0.9 * row["wave_gdof_s"]
 
 
 def test_benchmark05_headline_size(pkg, golden):
@@ -91,6 +98,27 @@ def test_benchmark02_and_03_device_columns(pkg, golden):
             assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
 
 
+def test_benchmark01_default_problem_size(pkg, golden):
+    """BASELINE configs[0] at its DEFAULT size: `benchmark01` with no arguments runs size = 1024 .. 536 870 912 doubles
+    (benchmark01/benchmark01.cc:343; 4.3 GB of host memory), host column on the granted cores and device column, and
+    both reproduce all 20 published norms (benchmark01/outfile.log) -- so config 0 rests on a run, not on a
+    committed log."""
+    import oracle
+    env = dict(os.environ, OMP_NUM_THREADS=str(oracle.usable_cpus()))
+    res = subprocess.run([os.path.join(BIN, "benchmark01")], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    log = pkg.logfmt.parse_log(res.stdout)
+    assert log.kind == "GB/s" and log.ncols == 2 and len(log.sizes) == 20
+    assert log.sizes[0] == 1024.0 and log.sizes[-1] == 536870912.0
+    want = {r["n"]: float(r["norm"]) for r in golden["l2norm"]["rows"]}
+    assert len(want) == 20
+    for size, norms, rates in zip(log.sizes, log.norms, log.values):
+        for v in norms:                                   # host AND device column
+            assert abs(v - want[int(size)]) <= 5.5e-10 * want[int(size)], (size, norms)
+        assert all(r > 0 for r in rates)
+    assert log.values[-1][1] > 2000.0                     # device column at 4.3 GB: measured 6.2-7.0 TB/s
+
+
 def test_bench_contract_single_gpu(pkg):
     """`python bench.py` (N = 1): one JSON line with the contract keys, the roofline and cpu_baseline
     objects, the golden-norm self check, and a loose performance floor (reference's best: 26.4)."""
@@ -113,6 +141,10 @@ def test_bench_contract_single_gpu(pkg):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert rec["golden_norm_check"]["ok"] is True
     assert set(rec["extra"]["hex_sweep"]) == {str(n) for n in range(2, 11)}
+    for entry in list(rec["extra"]["hex_sweep"].values()) + list(rec["extra"]["quad"].values()):
+        assert entry["frac"] == entry["frac_mean"] <= entry["frac_min"]       # one protocol per number
+    assert rec["ms_min_of_40"] <= rec["ms_mean_of_40_groups"] and rl["kernel_ms"] <= rec["ms_per_step"] * 1.001
+    assert {"26", "30"} <= set(rec["extra"]["quad"])
     assert rec["value"] > 150.0 and rl["frac"] > 0.35   # measured 280-300 / 0.70-0.74
 
 
@@ -123,7 +155,7 @@ def test_bench_two_ranks_rehearsal(pkg, tmp_path):
     env = dict(os.environ, SF_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "1", "--total-elements", "200001"]
+           "--gpus", "2", "--steps", "5", "--warmup", "1", "--total-elements", "200001", "--cpu-seconds", "2"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
@@ -133,6 +165,9 @@ def test_bench_two_ranks_rehearsal(pkg, tmp_path):
         assert key in rec, key
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["dtype"] == "f64"
     assert rec["config"]["total_elements"] == 200001 and rec["value"] > 1.0
+    # the N > 1 line carries the CPU baseline of the same run, per-GPU fractions and the speed-up over one GPU
+    assert rec["cpu_baseline"]["value"] > 0 and len(rec["roofline"]["per_gpu_frac"]) == 2
+    assert rec["speedup_vs_1gpu_same_batch"] > 0 and "traffic" in rec["roofline"]
     # the two shards together are the single-rank batch: same checksum as one rank over all elements
     x = pkg.fill_random(200001 * 343, 0x5F3759DF, 0)
     b = pkg.fill_basis(7, 8)
@@ -235,6 +270,13 @@ def test_benchmark05_ngpus_row(pkg, golden, tmp_path):
     assert log.values[0][3] > 100.0 * ndev and all(v == 0.0 for i, v in enumerate(log.values[0]) if i != 3)
     rec = json.loads(js.read_text())
     assert rec["ngpus"] == ndev and len(rec["rows"][0]["per_device_ms"]) == ndev
+    row = rec["rows"][0]
+    # the printed row is the host-wall figure (same clock as the single-GPU rows); events and the speed-up over device
+    # 0 alone on the same batch are in the side file
+    assert abs(row["wave_gdof_s"] - log.values[0][3]) <= 1e-6 * log.values[0][3]
+    assert row["wave_gdof_s_event"] >= 0.95 * row["wave_gdof_s"]
+    assert row["single_gpu_same_batch_gdof_s"] > 100.0 and row["speedup_vs_1gpu_same_batch"] > 0.5 * ndev
+    assert row["scaling_verified_on_hardware"] is (ndev > 1)
     # seeded data is generated from the global element index: the sharded norm equals the one-GPU norm
     res = subprocess.run([os.path.join(BIN, "benchmark05"), "8", "8", "8", "--nelmt", "300001", "--ngpus", str(ndev),
                           "--data", "random"], capture_output=True, text=True, timeout=600, env=env)

@@ -86,8 +86,10 @@ def test_quad_mfma4_parity_all_orders(sf, oracle, nq):
     for nelmt in (1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 129, 1000, 4099):
         err = _quad_case(sf, oracle, (nq, nq), nelmt, "mfma4", seed=nelmt + nq)
         assert err <= TOL, (nq, nelmt, err)
-    # more chunks than a persistent grid has waves (256 CUs x 4..8 waves), ragged tail, sin/cos basis
-    nelmt = 70001 if nq <= 24 else 20011
+    # more chunks than a persistent grid has waves (256 CUs x 4..8 waves), ragged tail, sin/cos basis; from nq 25 the
+    # grid draws batches of 4..8 chunks from a device-wide counter, two tickets up front per wave: 131 101 elements are
+    # 4 100+ batches against ~2 048 initial tickets, so every wave redeems tickets issued inside its loop
+    nelmt = 70001 if nq <= 24 else 131101
     b = sf.fill_basis(nq - 1, nq)
     x = sf.fill_random(nelmt * (nq - 1) ** 2, 77 + nq)
     got = sf.bwdtrans_quad((nq, nq), b, b, x, variant="mfma4")
@@ -358,6 +360,72 @@ def test_non_default_streams(sf, oracle, torch_mod):
     for x, o in zip(xs, outs):
         ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, _np(b), _np(b), _np(b), _np(x))
         assert oracle.rel_err(_np(o), ref) <= TOL
+
+
+def test_persistent_quad_kernels_are_capture_safe_from_the_first_call(sf, oracle, torch_mod):
+    """AUTO 2D nq 25..32 feed a persistent grid from a batch counter.  The counters live in a per-device buffer that is
+    never evicted (csrc/aux_kernels.hip counter_acquire): (a) a capture that PRECEDES the buffer's allocation runs the
+    fixed-share kernel instead of allocating inside the capture; (b) a launch captured later bakes a counter of its own,
+    which neither eager launches on other streams nor scratch churn on 200 more streams invalidate.  All replays
+    bit-identical to the eager result and within 1e-12 of the oracle."""
+    nq, nelmt = 28, 30011
+    lib = sf.capi.lib()
+    b = sf.fill_basis(nq - 1, nq)
+    x = sf.fill_random(nelmt * (nq - 1) ** 2, 5)
+    ref = oracle.bwdtrans_quad((nq, nq), nelmt, _np(b), _np(b), _np(x))
+    torch_mod.cuda.synchronize()
+    assert lib.sf_shutdown() == 0                       # drops the counter buffer: the next use is a FIRST use
+
+    def captured():
+        o = torch_mod.zeros(nelmt * nq * nq, dtype=torch_mod.float64, device="cuda")
+        side = torch_mod.cuda.Stream()
+        side.wait_stream(torch_mod.cuda.current_stream())
+        g = torch_mod.cuda.CUDAGraph()
+        with torch_mod.cuda.stream(side):
+            with torch_mod.cuda.graph(g, stream=side):
+                sf.bwdtrans_quad((nq, nq), b, b, x, out=o, stream=side)
+        torch_mod.cuda.current_stream().wait_stream(side)
+        return g, o
+
+    g1, o1 = captured()                                 # (a) first use of a counter inside a capture
+    g1.replay()
+    torch_mod.cuda.synchronize()
+    assert oracle.rel_err(_np(o1), ref) <= TOL
+    eager = sf.bwdtrans_quad((nq, nq), b, b, x)         # allocates the counter buffer
+    torch_mod.cuda.synchronize()
+    assert torch_mod.equal(eager, o1)
+    g2, o2 = captured()                                 # (b) a counter of its own, baked into the graph
+    streams = [torch_mod.cuda.Stream() for _ in range(200)]
+    small = sf.fill_random(4096, 9)
+    for st in streams:                                  # scratch churn: 200 streams > the 128 scratch slots
+        sf.sumsq(small, stream=st)
+        sf.bwdtrans_quad((nq, nq), b, b, x[:8 * (nq - 1) ** 2], stream=st)
+    torch_mod.cuda.synchronize()
+    for _ in range(3):
+        o2.zero_()
+        g2.replay()
+        other = sf.bwdtrans_quad((nq, nq), b, b, x, stream=streams[7])   # eager launch racing the replay
+        torch_mod.cuda.synchronize()
+        assert torch_mod.equal(o2, eager) and torch_mod.equal(other, eager)
+
+
+def test_launch_hint_belongs_to_the_calling_thread(sf, oracle):
+    """sf_set_launch_hint is per host thread (include/sumfact.h): a hint set by another thread does not reshape this
+    thread's launches -- observable through the block-glb variant, which refuses a workspace-less call only after
+    its launch shape is fixed; here simply: results stay right on both threads while they disagree about the hint."""
+    import threading
+    lib = sf.capi.lib()
+    errs = {}
+
+    def other():
+        lib.sf_set_launch_hint(64, 9)
+        errs["other"] = max(_hex_case(sf, oracle, (6, 6, 6), 301, v) for v in ("thread", "block-lds", "block-glb"))
+
+    t = threading.Thread(target=other)
+    t.start()
+    errs["main"] = max(_hex_case(sf, oracle, (6, 6, 6), 301, v) for v in ("thread", "block-lds", "block-glb"))
+    t.join()
+    assert errs["main"] <= TOL and errs["other"] <= TOL
 
 
 TOL32 = 2e-5   # fp32: eps = 6e-8, sums of up to 3*31 products with cancellation
