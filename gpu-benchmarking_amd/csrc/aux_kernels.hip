@@ -506,6 +506,7 @@ int counter_acquire(hipStream_t s, unsigned long long **out)
             (void)hipGetLastError();
             return SF_ENOMEM;
         }
+        (void)hipMemset(p, 0, (size_t)kCounterSlots * kCounterStride);
         r.base = static_cast<char *>(p);
     }
     unsigned slot = kCounterSlots;

@@ -13,6 +13,11 @@ namespace sf
 
 constexpr int kMaxDev = 64;
 
+static __global__ void counter_reset_kernel(unsigned long long *ctr)
+{
+    __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Persistent grid: as many workgroups as the device keeps resident (occupancy query, cached per
 // device), never more than there are chunks.  The caches are atomics: two host threads that race on the first launch
 // both run the query and store the same answer.
@@ -140,11 +145,11 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         unsigned long long *ctr = nullptr;
         if (counter_acquire(s, &ctr) != SF_OK)
             return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0>(a, s);
-        hipError_t e = hipMemsetAsync(ctr, 0, 8, s);
-        if (e != hipSuccess)
-            return (int)e;
+        // zeroed by a one-thread kernel, not a memset: under stream capture a memset node on a pointer INSIDE an
+        // allocation did not zero the counter on ROCm 7.2 (the replayed grid then saw a stale ticket and exited)
+        counter_reset_kernel<<<1, 1, 0, s>>>(ctr);
         kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr);
-        e = hipGetLastError();
+        hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
     }
     else

@@ -401,12 +401,13 @@ def test_persistent_quad_kernels_are_capture_safe_from_the_first_call(sf, oracle
         sf.sumsq(small, stream=st)
         sf.bwdtrans_quad((nq, nq), b, b, x[:8 * (nq - 1) ** 2], stream=st)
     torch_mod.cuda.synchronize()
-    for _ in range(3):
+    for rep in range(3):
         o2.zero_()
         g2.replay()
         other = sf.bwdtrans_quad((nq, nq), b, b, x, stream=streams[7])   # eager launch racing the replay
         torch_mod.cuda.synchronize()
-        assert torch_mod.equal(o2, eager) and torch_mod.equal(other, eager)
+        assert torch_mod.equal(other, eager), rep
+        assert torch_mod.equal(o2, eager), (rep, int((o2 != eager).sum()))
 
 
 def test_launch_hint_belongs_to_the_calling_thread(sf, oracle):
