@@ -12,7 +12,7 @@ import torch
 from . import capi
 
 VARIANTS = {"auto": 0, "wave": 1, "thread": 2, "block-lds": 3, "block-glb": 4, "generic": 5,
-            "mfma": 6, "mfma4": 7}
+            "mfma": 6, "mfma4": 7, "wave-rt": 8}
 
 
 def _stream(stream, device=None):

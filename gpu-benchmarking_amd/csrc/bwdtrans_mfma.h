@@ -27,57 +27,98 @@ namespace sf
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <int NQ, int EC> struct MfmaGeom
+// T = float runs the same two chained GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32, the fp32 vector rate: 2x the fp64
+// instruction).  Its A / B lane maps are the fp64 ones; its D map is the standard one, D[row = 4*(l>>4) + r][col = l&15]
+// (fp64: row = (l>>4) + 4r).  Register r of a step-1 tile therefore holds the W rows q = 16tm + 4g + r on lane group
+// g -- still directly a B operand of step 2 (lane group g supplies k index g), against an A operand that holds
+// B1[16tm + 4g + r][j]: the chaining survives, the k-steps of step 2 just visit q in the order r, r+4, r+8, r+12.
+// fp32 sums therefore run in that order inside a 16-row tile (tolerance 2e-5 in the tests; fp64 stays ascending).
+template <typename T> struct MfmaOp;
+template <> struct MfmaOp<double>
 {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // D register r of lane group g holds tile row ...; step-2 k-step `ks`, lane group g, contracts over q = ...
+    static constexpr __device__ __host__ int drow(int g, int r)
+    {
+        return g + 4 * r;
+    }
+};
+template <> struct MfmaOp<float>
+{
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static constexpr __device__ __host__ int drow(int g, int r)
+    {
+        return 4 * g + r;
+    }
+};
+
+template <int NQ, int EC, typename T = double> struct MfmaGeom
+{
+    static constexpr int VW  = 16 / (int)sizeof(T);
     static constexpr int NM  = NQ - 1;
     static constexpr int NMT = NM * NM, NQT = NQ * NQ;
     static constexpr int MT1 = cdiv(NM, 16); // q tiles of step 1
     static constexpr int NT  = cdiv(NQ, 16); // i tiles
     static constexpr int KS1 = cdiv(NM, 4);  // p steps
     static constexpr int MT2 = cdiv(NQ, 16); // j tiles
-    static constexpr int KS2 = cdiv(NM, 4);  // q steps: groups of four rows of step 1's D that hold a real q
+    // q steps of step 2: D registers of step 1 that hold a real q.  fp64: register r of tile tm holds rows 16tm + 4r + g
+    // (consecutive groups of four rows: ceil(nm / 4) steps); fp32: rows 16tm + 4g + r (a register holds a real row iff
+    // 16tm + r < nm: every register of a tile with at least four rows)
+    static constexpr int REM  = NM - 16 * (MT1 - 1);
+    static constexpr int KS2 = sizeof(T) == 8 ? cdiv(NM, 4) : 4 * (MT1 - 1) + (REM < 4 ? REM : 4);
     static constexpr int S   = NM + ((6 - NM % 4) % 4); // row stride, S % 4 == 2
     static constexpr int IN_DBL = EC * NMT;
-    static constexpr bool VEC2  = (IN_DBL % 2) == 0;
-    static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
+    static constexpr bool VEC2  = (IN_DBL % VW) == 0;
+    static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / VW, kWave) : cdiv(IN_DBL, kWave);
     // per-element LDS region: the padded input image; with OUTL the slab is reused for the chunk's output
-    // image (element e at e*nq^2) once step 1 has consumed the input, so a region also holds nq^2 doubles
-    static constexpr int ESTRIDE = ((NM * S > NQT ? NM * S : NQT) + 1) & ~1;
-    static constexpr int SLAB    = EC * ESTRIDE; // doubles per wave
+    // image (element e at e*nq^2) once step 1 has consumed the input, so a region also holds nq^2 scalars
+    static constexpr int ESTRIDE = ((NM * S > NQT ? NM * S : NQT) + VW - 1) / VW * VW;
+    static constexpr int SLAB    = EC * ESTRIDE; // scalars per wave
     static_assert(S % 4 == 2 && S >= NM, "row stride");
 };
 
-template <int NQ, int EC, int WPB> constexpr size_t mfma_lds_bytes()
+template <int NQ, int EC, int WPB, typename T = double> constexpr size_t mfma_lds_bytes()
 {
-    return sizeof(double) * (size_t)WPB * MfmaGeom<NQ, EC>::SLAB;
+    return sizeof(T) * (size_t)WPB * MfmaGeom<NQ, EC, T>::SLAB;
 }
 
 // staging registers -> LDS, element e row q at e*ESTRIDE + q*S
-template <class G>
-__device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double *slab, int lane, int sh)
+template <class G, typename T>
+__device__ __forceinline__ void mfma_stage(const typename VecOf<T>::type (&st)[G::NLD], T *slab, int lane, int sh)
 {
+    constexpr int VW = G::VW;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k)
     {
         const int v = k * kWave + lane;
         if constexpr (G::VEC2)
         {
-            if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+            if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
             {
-                const int f0 = 2 * v, f1 = 2 * v + 1;
-                const int r0 = f0 / G::NM, r1 = f1 / G::NM; // flat row index (e*NM + q)
-                const int e0 = r0 / G::NM, e1 = r1 / G::NM;
-                slab[e0 * G::ESTRIDE + (r0 - e0 * G::NM) * G::S + (f0 - r0 * G::NM)] = st[k].x;
-                slab[e1 * G::ESTRIDE + (r1 - e1 * G::NM) * G::S + (f1 - r1 * G::NM)] = st[k].y;
+#pragma unroll
+                for (int h = 0; h < VW; ++h)
+                {
+                    const int f = VW * v + h;
+                    const int r = f / G::NM, e = r / G::NM; // flat row index (e*NM + q)
+                    slab[e * G::ESTRIDE + (r - e * G::NM) * G::S + (f - r * G::NM)] = st[k][h];
+                }
             }
         }
-        else if (k < word_grid_regs<G::IN_DBL, double>())
+        else if (k < word_grid_regs<G::IN_DBL, T>())
         {
-            // word-grid registers (chunk_load_any): word v holds doubles 2v - sh + {0, 1}
+            // word-grid registers (chunk_load_any): word v holds scalars VW*v - sh + {0 .. VW-1}
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < VW; ++h)
             {
-                const int f = 2 * v - sh + h;
+                const int f = VW * v - sh + h;
                 if (f >= 0 && f < G::IN_DBL)
                 {
                     const int r0 = f / G::NM, e0 = r0 / G::NM;
@@ -88,19 +129,22 @@ __device__ __forceinline__ void mfma_stage(const double2_t (&st)[G::NLD], double
     }
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false, int XG = 0>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, bool OUTL = false, int XG = 0, typename T = double>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
-    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
-    double *__restrict__ out, uint64_t nelmt)
+    const T *__restrict__ b0, const T *__restrict__ b1, const T *__restrict__ in,
+    T *__restrict__ out, uint64_t nelmt)
 {
-    using G          = MfmaGeom<NQ, EC>;
+    using G          = MfmaGeom<NQ, EC, T>;
+    using Op         = MfmaOp<T>;
+    using acc_t      = typename Op::acc_t;
     constexpr int NM = G::NM;
 
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_mfma[];
+    T *lds = reinterpret_cast<T *>(lds_raw_mfma);
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int a = lane & 15, g = lane >> 4;
-    double *slab = lds + wib * G::SLAB;
+    T *slab = lds + wib * G::SLAB;
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
@@ -108,22 +152,23 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
         return;
 
     // bases as MFMA operands, zero outside nm x nq
-    double opB0[G::KS1][G::NT], opB1[G::KS2][G::MT2];
+    T opB0[G::KS1][G::NT], opB1[G::KS2][G::MT2];
 #pragma unroll
     for (int ks = 0; ks < G::KS1; ++ks)
 #pragma unroll
         for (int tn = 0; tn < G::NT; ++tn)
         {
             const int p = ks * 4 + g, i = tn * 16 + a;
-            opB0[ks][tn] = (p < NM && i < NQ) ? b0[p * NQ + i] : 0.0;
+            opB0[ks][tn] = (p < NM && i < NQ) ? b0[p * NQ + i] : T(0);
         }
 #pragma unroll
     for (int ks = 0; ks < G::KS2; ++ks)
 #pragma unroll
         for (int tm = 0; tm < G::MT2; ++tm)
         {
-            const int q = ks * 4 + g, j = tm * 16 + a;
-            opB1[ks][tm] = (q < NM && j < NQ) ? b1[q * NQ + j] : 0.0;
+            // the q this lane group contributes to q step ks = the row of step 1's D register ks % 4 of tile ks / 4
+            const int q = 16 * (ks / 4) + Op::drow(g, ks % 4), j = tm * 16 + a;
+            opB1[ks][tm] = (q < NM && j < NQ) ? b1[q * NQ + j] : T(0);
         }
 
     // A-operand gather offsets (clamped into the element: padding meets a zero basis entry)
@@ -135,9 +180,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
         arow[tm]    = (q < NM ? q : NM - 1) * G::S;
     }
 
-    using GW = WaveGeom<NQ, EC, 2>; // chunk_load only needs IN_DBL / NLD / NMT, identical here
+    using GW = WaveGeom<NQ, EC, 2, T>; // chunk_load only needs IN_DBL / NLD / NMT, identical here
     static_assert(GW::NLD == G::NLD && GW::IN_DBL == G::IN_DBL, "geometry mismatch");
-    double2_t st[G::NLD];
+    typename GW::Vec st[G::NLD];
     chunk_fetch<GW, EC>(st, in, it.first, nelmt, lane);
 
     uint64_t c = it.first;
@@ -146,7 +191,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
         const uint64_t left = nelmt - c * EC;
         const int evalid    = left >= EC ? EC : (int)left;
 
-        mfma_stage<G>(st, slab, lane, G::VEC2 ? 0 : line_offset<double>(in + c * G::IN_DBL));
+        mfma_stage<G, T>(st, slab, lane, G::VEC2 ? 0 : line_offset<T>(in + c * G::IN_DBL));
         wave_lds_fence();
         if (n + 1 < it.count)
             chunk_fetch<GW, EC>(st, in, c + it.step, nelmt, lane);
@@ -154,14 +199,14 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 #pragma unroll 1
         for (int e = 0; e < evalid; ++e)
         {
-            double *img = slab + e * G::ESTRIDE;
+            T *img = slab + e * G::ESTRIDE;
             // ---- step 1: W = In * B0 ------------------------------------------------------------
-            double4_t w[G::MT1][G::NT];
+            acc_t w[G::MT1][G::NT];
 #pragma unroll
             for (int tm = 0; tm < G::MT1; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < G::NT; ++tn)
-                    w[tm][tn] = double4_t{0.0, 0.0, 0.0, 0.0};
+                    w[tm][tn] = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int ks = 0; ks < G::KS1; ++ks)
             {
@@ -170,42 +215,40 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 #pragma unroll
                 for (int tm = 0; tm < G::MT1; ++tm)
                 {
-                    const double aop = img[arow[tm] + pc];
+                    const T aop = img[arow[tm] + pc];
 #pragma unroll
                     for (int tn = 0; tn < G::NT; ++tn)
-                        w[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, opB0[ks][tn], w[tm][tn],
-                                                                         0, 0, 0);
+                        w[tm][tn] = Op::mma(aop, opB0[ks][tn], w[tm][tn]);
                 }
             }
             // ---- step 2: Out = B1^T * W  (W straight from step 1's accumulators) ------------------
-            double4_t o[G::MT2][G::NT];
+            acc_t o[G::MT2][G::NT];
 #pragma unroll
             for (int tm = 0; tm < G::MT2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < G::NT; ++tn)
-                    o[tm][tn] = double4_t{0.0, 0.0, 0.0, 0.0};
+                    o[tm][tn] = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int ks = 0; ks < G::KS2; ++ks)
             {
 #pragma unroll
                 for (int tn = 0; tn < G::NT; ++tn)
                 {
-                    const double bop = w[ks / 4][tn][ks % 4];
+                    const T bop = w[ks / 4][tn][ks % 4];
 #pragma unroll
                     for (int tm = 0; tm < G::MT2; ++tm)
-                        o[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB1[ks][tm], bop, o[tm][tn],
-                                                                         0, 0, 0);
+                        o[tm][tn] = Op::mma(opB1[ks][tm], bop, o[tm][tn]);
                 }
             }
-            // ---- store: register r of tile (tm, tn) is Out[j = 16tm + g + 4r][i = 16tn + a] -------
-            double *oe = out + (c * EC + e) * (uint64_t)G::NQT;
+            // ---- store: register r of tile (tm, tn) is Out[j = 16tm + drow(g, r)][i = 16tn + a] ----
+            T *oe = out + (c * EC + e) * (uint64_t)G::NQT;
             if constexpr (OUTL)
             {
                 // the element's input image is dead (step 1 has read it): park the output in the slab at
                 // e*nq^2 -- never beyond the start of element e+1's still-live input image, since
                 // ESTRIDE >= nq^2 -- and let the whole chunk leave as one flat stream after the loop
                 wave_lds_fence();
-                double *oimg = slab + e * G::NQT;
+                T *oimg = slab + e * G::NQT;
 #pragma unroll
                 for (int tm = 0; tm < G::MT2; ++tm)
 #pragma unroll
@@ -213,7 +256,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                         {
-                            const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
+                            const int j = tm * 16 + Op::drow(g, r), i = tn * 16 + a;
                             if (j < NQ && i < NQ)
                                 oimg[j * NQ + i] = o[tm][tn][r];
                         }
@@ -227,7 +270,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                         {
-                            const int j = tm * 16 + g + 4 * r, i = tn * 16 + a;
+                            const int j = tm * 16 + Op::drow(g, r), i = tn * 16 + a;
                             if (j < NQ && i < NQ)
                                 __builtin_nontemporal_store(o[tm][tn][r], oe + j * NQ + i);
                         }

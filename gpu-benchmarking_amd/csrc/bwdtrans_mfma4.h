@@ -77,7 +77,13 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // (`next_batch`, zeroed before the launch) instead of a fixed share: a fixed share makes the launch as slow as its
 // slowest wave, and waves do not run at equal speed (their CU's neighbours, their XCD's memory channels).  One
 // address takes ~80 M atomics/s on this part, hence batches; the counter is read a whole batch ahead.
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0>
+// PEEL: where nm leaves a remainder of one or two rows over a multiple of four (nm = 25, 26, 29, 30: nq = 26, 27, 30, 31)
+// the last 4-wide k step of BOTH contractions is all but empty.  Those one or two p (step 1) / q (step 2) go through
+// the vector pipe instead -- one v_fma_f64 per accumulator and remaining k, against a 16-clock product per accumulator
+// for the padded step -- which removes 1/TQ (12-14 %) of the matrix instructions; the chip sustains a fixed rate of
+// issued fp64 matrix work next to the memory stream, so fewer issued products is what moves these orders.
+// The sums stay in ascending order of p and q (matrix steps first, the peeled remainder last).
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr)
@@ -85,6 +91,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     using G  = Mfma4Geom<NQ, EB>;
     using GW = WaveGeom<NQ, EB, 2>; // chunk_load / chunk_flush geometry (IN_DBL, NLD, OUT_DBL)
     constexpr int NM = G::NM, IB = G::IB, TQ = G::TQ, TI = G::TI, TG = G::TG, BS = G::BS;
+    constexpr int RQ = (PEEL && (NM % 4 == 1 || NM % 4 == 2)) ? NM % 4 : 0; // p / q values contracted on the vector pipe
+    constexpr int KQ = RQ ? NM / 4 : TQ;                                     // 4-wide k steps on the matrix pipe
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bl0 = lds, *bl1 = SHB ? lds : lds + G::NBAS;
@@ -243,9 +251,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             };
             request(0, 0);
 #pragma unroll
-            for (int tp = 0; tp < TQ; ++tp)
+            for (int tp = 0; tp < KQ; ++tp)
             {
-                if (tp + 1 < TQ)
+                if (tp + 1 < KQ)
                     request((tp + 1) & 1, tp + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -255,6 +263,49 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                         w[tq][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[tp & 1][tq], bt[tp & 1][ig], w[tq][ig], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (RQ > 0)
+            {
+                // peeled p: W[q = 4tq + hi][i] += In[q][p] * B0[p][i] on the accumulators' own lanes (row on hi, column
+                // on lo); rows beyond nm are padding and read a clamped (finite) row
+                double ain[RQ][TQ], bin[RQ][TG];
+#pragma unroll
+                for (int d = 0; d < RQ; ++d)
+                {
+#pragma unroll
+                    for (int tq = 0; tq < TQ; ++tq)
+                    {
+                        const int q = 4 * tq + hi;
+                        ain[d][tq]  = slab[e * G::ESTR + (q < NM ? q : NM - 1) * G::S + 4 * KQ + d];
+                    }
+#pragma unroll
+                    for (int ig = 0; ig < TG; ++ig)
+                        bin[d][ig] = bl0[(4 * KQ + d) * BS + 4 * (IB * ig + ib) + lo];
+                }
+#pragma unroll
+                for (int d = 0; d < RQ; ++d)
+#pragma unroll
+                    for (int ig = 0; ig < TG; ++ig)
+#pragma unroll
+                        for (int tq = 0; tq < TQ; ++tq)
+                            w[tq][ig] = __builtin_fma(ain[d][tq], bin[d][ig], w[tq][ig]);
+            }
+        }
+        // peeled q: row q = 4 KQ + d of W sits in w[TQ - 1] on the lanes with hi == d; every lane needs it for its own
+        // column, i.e. from lane 16 d + (lane & 15)
+        double wf[RQ > 0 ? RQ : 1][TG];
+        if constexpr (RQ > 0)
+        {
+#pragma unroll
+            for (int d = 0; d < RQ; ++d)
+#pragma unroll
+                for (int ig = 0; ig < TG; ++ig)
+                {
+                    const int src = 4 * (16 * d + (lane & 15));
+                    const double v = w[TQ - 1][ig];
+                    const int vlo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+                    const int vhi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+                    wf[d][ig]     = __hiloint2double(vhi, vlo);
+                }
         }
         wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
 
@@ -280,9 +331,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                 };
                 request(0, 0);
 #pragma unroll
-                for (int tq = 0; tq < TQ; ++tq)
+                for (int tq = 0; tq < KQ; ++tq)
                 {
-                    if (tq + 1 < TQ)
+                    if (tq + 1 < KQ)
                         request((tq + 1) & 1, tq + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -295,6 +346,22 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                             o[t][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[tq & 1][t], w[tq][ig], o[t][ig], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (RQ > 0)
+                {
+                    // peeled q: Out[j = 4tj + hi][i] += B1[q][j] * W[q][i]
+#pragma unroll
+                    for (int d = 0; d < RQ; ++d)
+#pragma unroll
+                        for (int t = 0; t < GJ; ++t)
+                        {
+                            if (j0 + t >= TI)
+                                continue;
+                            const double bq = bl1[(4 * KQ + d) * BS + 4 * (j0 + t) + hi];
+#pragma unroll
+                            for (int ig = 0; ig < TG; ++ig)
+                                o[t][ig] = __builtin_fma(bq, wf[d][ig], o[t][ig]);
+                        }
                 }
 #pragma unroll
                 for (int t = 0; t < GJ; ++t)

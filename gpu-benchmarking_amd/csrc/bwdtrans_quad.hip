@@ -4,6 +4,8 @@
 #include "wave_launch.h"
 #include "wave_table.h"
 
+#include <cstdlib>
+
 namespace sf
 {
 
@@ -78,6 +80,10 @@ __global__ __launch_bounds__(256) void quad_nq2_stream_f32_kernel(const float *_
     }
 }
 
+// fp32 orders from here on run the matrix-core kernel: its 16-wide tiles are (nearly) full there, and the vector kernel
+// is issue-bound (0.41-0.52 of the roofline at nq 25..32, profiles/r02/sweep_auto_f32.log)
+constexpr int kQuadF32MfmaFrom = 25;
+
 template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
 {
     if constexpr (NQ == 2)
@@ -91,11 +97,37 @@ template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
     }
-    using C = QuadCfgF32<NQ>;
-    return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
+    if constexpr (NQ >= kQuadF32MfmaFrom)
+    {
+        // v_mfma_f32_16x16x4_f32 (bwdtrans_mfma.h, T = float): two-element chunks, LDS-staged line-aligned output where the
+        // rows are not whole lines, two waves per SIMD, XCD runs
+        // per order the best of tools/experiments/f32_mfma_cfg.sh (profiles/r03/f32_mfma_configurations.log; fraction of
+        // the fp32 HBM roofline at 1 Mi elements, vector kernel in brackets): 25 0.542 (0.506)  26 0.529 (0.509)
+        // 27 0.564 (0.496)  28 0.570 (0.514)  29 0.609 (0.517)  30 0.571 (0.512)  31 0.636 (0.505)  32 0.641 (0.416)
+        constexpr int best = (NQ == 25 || NQ == 26) ? 3 : ((NQ == 28 || NQ == 32) ? 2 : (NQ == 30 ? 4 : (NQ == 27 ? 0 : 1)));
+        static const int cfg = getenv("SF_F32_MFMA_CFG") ? atoi(getenv("SF_F32_MFMA_CFG")) : best; // development knob
+        switch (cfg)
+        {
+        case 1: return launch_quad_mfma<NQ, 2, 4, 4, 2, (NQ != 32), 64, float>(a, s);
+        case 2: return launch_quad_mfma<NQ, 4, 4, 2, 1, (NQ != 32), 64, float>(a, s);
+        case 3: return launch_quad_mfma<NQ, 4, 4, 4, 1, (NQ != 32), 64, float>(a, s);
+        case 4: return launch_quad_mfma<NQ, 2, 4, 4, 1, (NQ != 32), 64, float>(a, s);
+        case 5:
+        {
+            using C = QuadCfgF32<NQ>;
+            return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
+        }
+        default: return launch_quad_mfma<NQ, 2, 4, 2, 2, (NQ != 32), 64, float>(a, s);
+        }
+    }
+    else
+    {
+        using C = QuadCfgF32<NQ>;
+        return launch_quad_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);
+    }
 }
 
-// fp32 (T = float): the vector-ALU kernel for every order 2..32 (no fp32 matrix-core variant)
+// fp32 (T = float): the vector-ALU kernel up to nq = kQuadF32MfmaFrom - 1, the fp32 matrix-core kernel above
 int launch_quad_wave_f32_nq(unsigned nq, const QuadArgsT<float> &a, hipStream_t s)
 {
     switch (nq)

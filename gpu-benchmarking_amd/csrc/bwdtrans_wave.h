@@ -356,6 +356,47 @@ __device__ __forceinline__ void chunk_stage(const typename G::Vec (&st)[G::NLD],
     }
 }
 
+// One basis row of a contraction: acc[pass][N0 + n] (+)= u[pass][m] * b[n], n < NB (m == 0 starts the sums).
+// T = double: one v_fma_f64 per value.  T = float: neighbouring outputs n, n + 1 share one v_pk_fma_f32 -- the pencil
+// value is broadcast to both halves (op_sel), the two basis entries are an SGPR (or VGPR) pair -- so the fp32 sweeps
+// issue half the vector instructions; from 2D nq = 17 / 3D nq = 11 they are issue-bound, not memory-bound
+// (profiles/r02/sweep_auto_f32.log).  Same products, same ascending order of m: results do not change.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <int NB, int N0, int NOUT, int NPASS>
+__device__ __forceinline__ void fma_row(bool first, const double (&um)[NPASS], const double (&b)[NB],
+                                        double (&acc)[NPASS][NOUT])
+{
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s)
+            acc[s][N0 + n] = first ? um[s] * b[n] : fma_t(um[s], b[n], acc[s][N0 + n]);
+}
+template <int NB, int N0, int NOUT, int NPASS>
+__device__ __forceinline__ void fma_row(bool first, const float (&um)[NPASS], const float (&b)[NB],
+                                        float (&acc)[NPASS][NOUT])
+{
+    // measured per order (profiles/r03/sweep_auto_f32_packed.log against r02's): +7..14 % where the sweeps are issue-bound
+    // (2D nq 17..24, 3D nq 9..16), neutral below, -3..8 % at 2D nq 25..31 (two-element chunks at full occupancy)
+    constexpr int NPAIR = (NOUT >= 9 && NOUT <= 24) ? NB / 2 : 0;
+#pragma unroll
+    for (int n = 0; n < 2 * NPAIR; n += 2)
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s)
+        {
+            const float2_t uu = {um[s], um[s]}, bb = {b[n], b[n + 1]};
+            const float2_t a  = {acc[s][N0 + n], acc[s][N0 + n + 1]};
+            const float2_t r  = first ? uu * bb : __builtin_elementwise_fma(uu, bb, a);
+            acc[s][N0 + n]     = r.x;
+            acc[s][N0 + n + 1] = r.y;
+        }
+#pragma unroll
+    for (int n = 2 * NPAIR; n < NB; ++n)
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s)
+            acc[s][N0 + n] = first ? um[s] * b[n] : fma_t(um[s], b[n], acc[s][N0 + n]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // BASIS_SMEM_COLS: columns [N0, N0+NB) of every basis row through a two-deep SGPR ring, then the next
 // column block (same touch / request / FMA / fence order per row as contract() below)
@@ -382,12 +423,13 @@ __device__ __forceinline__ void contract_cols(const T (&u)[NPASS][NIN], T (&acc)
                 b[(m + 1) % 2][n] = bas[zero + (m + 1) * NOUT + N0 + n];
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
+        {
+            T um[NPASS];
 #pragma unroll
             for (int s = 0; s < NPASS; ++s)
-                acc[s][N0 + n] = (m == 0) ? u[s][0] * b[0][n]
-                                          : fma_t(u[s][m], b[m % 2][n], acc[s][N0 + n]);
+                um[s] = u[s][m];
+            fma_row<NB, N0>(m == 0, um, b[m % 2], acc);
+        }
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -446,13 +488,12 @@ __device__ __forceinline__ void contract(const T (&u)[NPASS][NIN], T (&acc)[NPAS
             // before the next wait and the latency is exposed again)
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int n = 0; n < NOUT; ++n)
         {
+            T um[NPASS];
 #pragma unroll
             for (int s = 0; s < NPASS; ++s)
-                acc[s][n] = (m == 0) ? u[s][0] * b[0][n]
-                                     : fma_t(u[s][m], b[m % RING][n], acc[s][n]);
+                um[s] = u[s][m];
+            fma_row<NOUT, 0>(m == 0, um, b[m % RING], acc);
         }
         // order fence: the next row's operand loads (addressed through `zero`) may not be issued
         // before this row's FMAs, and this row's FMAs may not sink below them

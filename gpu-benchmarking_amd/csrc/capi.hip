@@ -37,7 +37,8 @@ const char *sf_error_string(int rc)
 const char *sf_variant_name(int variant)
 {
     static const char *names[SF_NUM_VARIANTS] = {"auto",      "wave",    "thread", "block-lds",
-                                                 "block-glb", "generic", "mfma",   "mfma4"};
+                                                 "block-glb", "generic", "mfma",   "mfma4",
+                                                 "wave-rt"};
     return (variant >= 0 && variant < SF_NUM_VARIANTS) ? names[variant] : "?";
 }
 
@@ -72,14 +73,23 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
+        // anisotropic extents, or buffers that are only 8-byte aligned: the run-time-extent wave kernel up to nq = 16
+        // per direction (bwdtrans_rt.h), the barrier-per-sweep block kernel beyond
+        int rc = (!iso && vec_ok) ? launch_hex_wave3(nq0, nq1, nq2, a, s) : SF_ENOTBUILT; // compile-time triples
+        // the run-time-extent kernel is ahead of the block kernel up to nq = 8 per direction (0.39-0.52 of the roofline
+        // against 0.28-0.34; above that its unrolled-to-the-bound loops lose: profiles/r03/anisotropic_shapes.log)
+        if (rc == SF_ENOTBUILT && nq0 <= 8 && nq1 <= 8 && nq2 <= 8)
+            rc = launch_hex_rt(nq0, nq1, nq2, a, s);
+        if (rc != SF_ENOTBUILT)
+            return rc;
         return launch_hex_generic(SF_VARIANT_GENERIC, nq0, nq1, nq2, a, s);
     }
+    case SF_VARIANT_WAVE_RT:
+        return launch_hex_rt(nq0, nq1, nq2, a, s);
     case SF_VARIANT_WAVE:
-        if (!iso)
-            return SF_ENOTBUILT;
         if (!vec_ok)
             return SF_EALIGN;
-        return launch_hex_wave_nq(nq0, a, s);
+        return iso ? launch_hex_wave_nq(nq0, a, s) : launch_hex_wave3(nq0, nq1, nq2, a, s);
     case SF_VARIANT_MFMA:
         if (!iso)
             return SF_ENOTBUILT;

@@ -18,6 +18,8 @@ bool quad_prefers_mfma(unsigned nq);
 int quad_auto_kernel(unsigned nq);
 int launch_hex_generic(int variant, unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a,
                        hipStream_t s);
+int launch_hex_wave3(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
+int launch_hex_rt(unsigned nq0, unsigned nq1, unsigned nq2, const HexArgs &a, hipStream_t s);
 int launch_quad_generic(int variant, unsigned nq0, unsigned nq1, const QuadArgs &a, hipStream_t s);
 int sumsq_async(const double *x, size_t n, double *result_dev, hipStream_t s);
 int sumsq_blocking(const double *x, size_t n, double *result_host, hipStream_t s);

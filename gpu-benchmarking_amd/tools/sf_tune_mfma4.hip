@@ -92,7 +92,7 @@ template <class F> static void run(const char *label, const QuadArgs &a, F launc
     std::fflush(stdout);
 }
 
-template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0> static void m4(const QuadArgs &a)
+template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEEL = true> static void m4(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
     if constexpr (mfma4_lds_bytes<NQ, EB, WPB, true>() <= 160 * 1024 && mfma4_lds_bytes<NQ, EB, WPB>() > 160 * 1024)
@@ -105,9 +105,9 @@ template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0> static v
     else if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
     {
         char label[96];
-        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d dyn%d lds %zu", NQ, EB, WPB, MW, GJ, K,
-                      XG, DYNB, mfma4_lds_bytes<NQ, EB, WPB>());
-        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB>(a, 0); });
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d dyn%d%s lds %zu", NQ, EB, WPB, MW, GJ, K,
+                      XG, DYNB, PEEL ? "" : " nopeel", mfma4_lds_bytes<NQ, EB, WPB>());
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB, PEEL>(a, 0); });
     }
 }
 
@@ -144,11 +144,23 @@ int main(int argc, char **argv)
         m4<2, 4, 2, 4, 2, 64>(a);
         m4<2, 4, 2, 4, 0, 0>(a);
         m4<2, 4, 2, 4, 0, 0, 4>(a);
+        m4<2, 4, 2, 4, 0, 0, 4, false>(a); // the same without the peeled k remainder (differs at nm = 1, 2 mod 4 only)
+        m4<2, 4, 2, 4, 1, 64, 0, false>(a);
         m4<2, 4, 2, 4, 0, 0, 8>(a);
         m4<2, 8, 2, 4, 0, 0, 8>(a);
         m4<4, 4, 1, 4, 0, 0>(a);
         m4<4, 4, 1, 4, 0, 0, 4>(a);
         m4<4, 4, 1, 4, 0, 0, 8>(a);
+        // short-lived workgroups at more independent phases per CU (round 3): one element per wave at 3 / 4 waves per
+        // SIMD, two-wave and one-wave workgroups of two-element chunks
+        m4<1, 4, 4, 4, 1, 64>(a);
+        m4<1, 4, 3, 4, 1, 64>(a);
+        m4<1, 4, 4, 4, 2, 64>(a);
+        m4<1, 8, 4, 4, 1, 64>(a);
+        m4<2, 2, 2, 4, 1, 64>(a);
+        m4<2, 1, 2, 4, 1, 64>(a);
+        m4<2, 3, 3, 4, 1, 64>(a);
+        m4<2, 2, 2, 4, 2, 64>(a);
     }
     return 0;
 }

@@ -38,7 +38,7 @@ def test_version_and_strings(pkg):
     assert lib.sf_version() == 100
     assert lib.sf_error_string(0) == b"success"
     assert b"invalid" in lib.sf_error_string(-1)
-    names = [lib.sf_variant_name(i).decode() for i in range(8)]
+    names = [lib.sf_variant_name(i).decode() for i in range(9)]
     assert names == list(pkg.VARIANTS)
 
 

@@ -109,6 +109,64 @@ def test_hex_mfma_parity_all_orders(sf, oracle, nq):
             assert err <= TOL, (nq, nelmt, err)
 
 
+RT_SHAPES = [(8, 8, 4), (4, 8, 6), (10, 6, 8), (2, 2, 2), (2, 16, 3), (16, 2, 2), (3, 2, 5), (7, 7, 7), (5, 9, 13),
+             (16, 16, 16), (15, 16, 14), (12, 3, 9)]
+
+
+@pytest.mark.parametrize("nq", RT_SHAPES)
+def test_hex_runtime_extent_wave_kernel(sf, oracle, nq):
+    """The wave-per-chunk kernel with RUN-TIME extents (csrc/bwdtrans_rt.h; what AUTO runs for anisotropic 3D extents
+    up to 16, benchmark05/benchmark05.cc:291-297 takes them at run time): ragged element counts around its chunk sizes,
+    explicit variant and AUTO, against the oracle."""
+    for nelmt in (1, 2, 3, 5, 15, 16, 17, 63, 64, 65, 257, 1000):
+        err = _hex_case(sf, oracle, nq, nelmt, "wave-rt", seed=nelmt)
+        assert err <= TOL, (nq, nelmt, err)
+    assert _hex_case(sf, oracle, nq, 4099, "auto", seed=3) <= TOL
+
+
+TRIPLES = [(8, 8, 4), (8, 4, 8), (4, 8, 8), (4, 8, 6), (4, 6, 8), (8, 4, 6), (8, 6, 4), (6, 4, 8), (6, 8, 4), (10, 6, 8),
+           (10, 8, 6), (6, 10, 8), (6, 8, 10), (8, 10, 6), (8, 6, 10), (8, 8, 6), (8, 6, 8), (6, 8, 8), (6, 6, 8), (6, 8, 6),
+           (8, 6, 6), (8, 8, 10), (8, 10, 8), (10, 8, 8), (10, 10, 8), (10, 8, 10), (8, 10, 10), (6, 6, 4), (6, 4, 6),
+           (4, 6, 6), (4, 4, 6), (4, 6, 4), (6, 4, 4)]
+
+
+@pytest.mark.parametrize("nq", TRIPLES)
+def test_hex_compile_time_anisotropic_triples(sf, oracle, nq):
+    """csrc/bwdtrans_wave3.h: the flagship wave-per-chunk kernel instantiated for anisotropic extents (the table in
+    csrc/bwdtrans_rt.hip; SF_VARIANT_WAVE with nq0 != nq1 != nq2, and what AUTO picks for these shapes): ragged element
+    counts around the chunk sizes 1..8, a batch with a partial XCD window, against the oracle."""
+    for nelmt in (1, 2, 3, 4, 5, 7, 8, 9, 15, 17, 63, 65, 257, 1000):
+        err = _hex_case(sf, oracle, nq, nelmt, "wave", seed=nelmt)
+        assert err <= TOL, (nq, nelmt, err)
+    assert _hex_case(sf, oracle, nq, 12345, "auto", seed=5) <= TOL
+
+
+def test_anisotropic_shape_outside_the_table_is_not_built_as_wave(sf):
+    b = [sf.fill_basis(q - 1, q) for q in (5, 9, 13)]
+    with pytest.raises(sf.capi.SumfactError) as ei:
+        sf.bwdtrans_hex((5, 9, 13), *b, sf.fill_random(4 * 8 * 12 * 3, 1), variant="wave")
+    assert ei.value.rc == sf.capi.SF_ENOTBUILT
+
+
+def test_hex_runtime_extent_kernel_on_8_byte_aligned_views(sf, oracle, torch_mod):
+    """`in` / `out` that are only 8-byte aligned (odd offsets into a larger buffer): chunks then start on either half
+    of a 16-byte word; guard words either side of the output stay untouched."""
+    for nq, nelmt in (((8, 8, 4), 333), ((4, 8, 6), 1001), ((3, 3, 3), 77), ((8, 8, 8), 129)):
+        nm = [q - 1 for q in nq]
+        nmt, nqt = nm[0] * nm[1] * nm[2], nq[0] * nq[1] * nq[2]
+        bs = [sf.fill_random(nm[d] * nq[d], 300 + d) for d in range(3)]
+        for off_in, off_out in ((1, 0), (0, 1), (1, 1), (3, 5)):
+            xbuf = sf.fill_random(nelmt * nmt + 8, 17 + off_in)
+            x = xbuf[off_in:off_in + nelmt * nmt]
+            obuf = torch_mod.full((nelmt * nqt + 16,), 7.25, dtype=torch_mod.float64, device="cuda")
+            o = obuf[off_out:off_out + nelmt * nqt]
+            sf.bwdtrans_hex(nq, *bs, x, out=o, variant="auto")
+            torch_mod.cuda.synchronize()
+            ref = oracle.bwdtrans_hex(tuple(nq), nelmt, *[_np(b) for b in bs], _np(x))
+            assert oracle.rel_err(_np(o), ref) <= TOL, (nq, off_in, off_out)
+            assert bool((obuf[:off_out] == 7.25).all()) and bool((obuf[off_out + nelmt * nqt:] == 7.25).all())
+
+
 def test_mfma_not_built_cases(sf):
     capi = sf.capi
     b = sf.fill_basis(7, 8)
