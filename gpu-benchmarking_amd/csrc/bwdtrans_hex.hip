@@ -124,11 +124,17 @@ template <int NQ> static int go_mfma(const HexArgs &a, hipStream_t s)
     else
     {
         // One element's LDS image is 11-32 KB here, so LDS -- not registers -- bounds the residency: one
-        // element per wave and small workgroups keep 5-12 waves per CU in flight (chunks of 2 left 2-3).
-        // profiles/r01/tune_hex1[1-6]_mfma.log: 265 / 313 / 266 / 283 / 252 / 286 GDOF/s at nq = 11..16
-        // (chunks of 2: 212 / 211 / 255 / 132 / 138 / 162).
-        constexpr int WPB = NQ == 11 ? 4 : (NQ <= 12 ? 2 : 1);
-        return launch_hex_mfma<NQ, 1, WPB, 2, 1, 64>(a, s);
+        // element per wave and one-wave workgroups keep 5-12 waves per CU in flight (chunks of 2 left 2-3).
+        // Round 3, sweeps 1 and 2 fused (profiles/r03/tune_hex1[2-6]_fused_sweeps.log, 131 072 elements, mean GDOF/s and
+        // fraction of the HBM roofline): 12: 323 = 0.74, 13: 335 = 0.76, 14: 292 = 0.66, 15: 293 = 0.65, 16: 309 = 0.68
+        // (unfused: 0.71 / 0.75 / 0.68 / 0.64 / 0.66, with 256 VGPRs and a scratch spill at nq = 16).  Several elements
+        // per wave with the next one's loads in flight (K = 2, 4, persistent) change nothing.  At nq = 14 the kernel issues
+        // 156 tile products of 2048 flops per element for 199 kflop of useful work (13 and 14 pad to 16 in every
+        // direction), i.e. 42 TFLOP/s issued at the measured rate -- the fp64 matrix rate this chip holds next to its
+        // memory stream; nq = 16 (tiles 92 % full) is bounded by its 32 KB LDS image: five waves per CU.
+        constexpr int WPB = NQ == 11 ? 4 : 1;
+        constexpr int MW  = (NQ == 14 || NQ == 15) ? 2 : 1;
+        return launch_hex_mfma<NQ, 1, WPB, MW, 1, 64>(a, s);
     }
 }
 

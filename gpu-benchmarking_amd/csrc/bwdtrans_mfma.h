@@ -325,6 +325,18 @@ template <int NQ, int EC> struct HexMfmaGeom
     static constexpr int SLAB    = EC * ESTRIDE;
     static_assert(NQ <= 16, "one 16-wide tile per direction");
     static_assert(S % 4 == 2 && W2S % 32 == 16 && W2S >= NQ2, "LDS strides");
+    // The tile of sweep 1 after which W2[r] may be written to its LDS row [r*W2S, r*W2S + NQ2): its own last q group
+    // must be in, and the row overlaps the input image (rows (r',q') at (r'*NM + q')*S), whose last overlapped row
+    // must have been gathered -- sweep 1 gathers input row (r',q') in tile (r'*QP + q') / 16.
+    static constexpr int w2_store_tile(int r)
+    {
+        const int own  = (r * QP + QP - 1) / 16;
+        int fr         = (r * W2S + NQ2 - 1) / S; // last overlapped flat input row
+        fr             = fr < NM * NM - 1 ? fr : NM * NM - 1;
+        const int need = ((fr / NM) * QP + fr % NM) / 16;
+        const int t    = own > need ? own : need;
+        return t < MT1 - 1 ? t : MT1 - 1;
+    }
 };
 
 template <int NQ, int EC, int WPB> constexpr size_t hex_mfma_lds_bytes()
@@ -445,46 +457,60 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
         for (int e = 0; e < evalid; ++e)
         {
             double *img = slab + e * G::ESTRIDE;
-            // ---- sweep 1 ------------------------------------------------------------------------
-            double4_t w1[G::MT1];
-#pragma unroll
-            for (int t = 0; t < G::MT1; ++t)
-                w1[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < G::KS1; ++ks)
-            {
-                const int p  = ks * 4 + g;
-                const int pc = p < NM ? p : NM - 1;
-#pragma unroll
-                for (int t = 0; t < G::MT1; ++t)
-                    w1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(img[arow[t] + pc], opB0[ks], w1[t], 0, 0, 0);
-            }
-            // ---- sweep 2: per r, B operand = register (R0 % 16) / 4 of tile R0 / 16, R0 = r*QP + 4*qs
+            // ---- sweeps 1 and 2, fused tile by tile ------------------------------------------------------------
+            // Sweep 1 produces one 16-row tile of W1 at a time; its four row groups are consumed at once as k-steps of
+            // sweep 2 (tile t, group gr holds rows R0 = 16t + 4gr .. +3 = four consecutive q of r = R0 / QP), so only ONE
+            // W1 tile is ever live (the unfused form kept all nm*QP/16 tiles and all nm W2 accumulators: 256 VGPRs and a
+            // scratch spill at nq = 16).  W2[r] goes to its LDS row [r][pos = j*NQ + i] as soon as (a) its last q group
+            // is in and (b) every input row that LDS row overlaps has been gathered (w2_store_tile): q and r stay in
+            // ascending order, so the sums are the unfused kernel's bit for bit.
             double4_t w2[NM];
 #pragma unroll
-            for (int r = 0; r < NM; ++r)
+            for (int t = 0; t < G::MT1; ++t)
             {
-                w2[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+                double4_t w1t = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int qs = 0; qs < G::KS2; ++qs)
+                for (int ks = 0; ks < G::KS1; ++ks)
                 {
-                    const int R0 = r * QP + 4 * qs;
-                    w2[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB1[qs], w1[R0 / 16][(R0 % 16) / 4],
-                                                                 w2[r], 0, 0, 0);
+                    const int p  = ks * 4 + g;
+                    const int pc = p < NM ? p : NM - 1;
+                    w1t = __builtin_amdgcn_mfma_f64_16x16x4f64(img[arow[t] + pc], opB0[ks], w1t, 0, 0, 0);
+                }
+#pragma unroll
+                for (int gr = 0; gr < 4; ++gr)
+                {
+                    const int R0 = 16 * t + 4 * gr;
+                    if (R0 < G::M1)
+                    {
+                        const int r = R0 / QP, qs = (R0 % QP) / 4;
+                        if (qs == 0)
+                            w2[r] = double4_t{0.0, 0.0, 0.0, 0.0};
+                        w2[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB1[qs], w1t[gr], w2[r], 0, 0, 0);
+                    }
+                }
+                // W2 rows that may leave now; lane (g,a), register r4 holds j = g + 4*r4, i = a
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < NM; ++r)
+                    any = any || G::w2_store_tile(r) == t;
+                if (any)
+                {
+                    wave_lds_fence(); // the gathers of tiles 0..t have completed
+#pragma unroll
+                    for (int r = 0; r < NM; ++r)
+                        if (G::w2_store_tile(r) == t)
+                        {
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4)
+                            {
+                                const int j = g + 4 * r4;
+                                if (j < NQ && a < NQ)
+                                    img[r * G::W2S + j * NQ + a] = w2[r][r4];
+                            }
+                        }
+                    wave_lds_fence();
                 }
             }
-            // ---- W2 -> LDS [r][pos = j*NQ + i]; lane (g,a), register r4 holds j = g + 4*r4, i = a --------
-            wave_lds_fence(); // every sweep-1 gather of this element has completed
-#pragma unroll
-            for (int r = 0; r < NM; ++r)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                {
-                    const int j = g + 4 * r4;
-                    if (j < NQ && a < NQ)
-                        img[r * G::W2S + j * NQ + a] = w2[r][r4];
-                }
-            wave_lds_fence();
             // ---- sweep 3 ------------------------------------------------------------------------
             double4_t o[G::CB];
 #pragma unroll

@@ -125,16 +125,16 @@ template <int NQ, int EC, int WPB, int MW, int KM, bool OL = false> void quad_mf
         a.nelmt * (size_t)NQ * NQ, [&]() { return launch_quad_mfma<NQ, EC, WPB, MW, KM, OL>(a, 0); });
 }
 
-template <int NQ, int EC, int WPB, int MW, int KM> void hex_mfma_case(const HexArgs &a)
+template <int NQ, int EC, int WPB, int MW, int KM, int XG = 0> void hex_mfma_case(const HexArgs &a)
 {
     char label[96];
-    std::snprintf(label, sizeof label, "hex nq%d MFMA EC%d WPB%d MW%d K%d", NQ, EC, WPB, MW, KM);
+    std::snprintf(label, sizeof label, "hex nq%d MFMA EC%d WPB%d MW%d K%d xg%d", NQ, EC, WPB, MW, KM, XG);
     const double nm = NQ - 1;
     if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
                     sizeof(double) * (NQ - 1) * NQ))
         return;
     run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
-        a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma<NQ, EC, WPB, MW, KM>(a, 0); });
+        a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma<NQ, EC, WPB, MW, KM, XG>(a, 0); });
 }
 
 int main(int argc, char **argv)
@@ -175,6 +175,7 @@ int main(int argc, char **argv)
 #define H(NQ, EC, WPB, BM, MW, KM, OUT) hex_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
 #define HM(NQ, EC, WPB, BM, MW, KM, OUT, MF) hex_case<NQ, EC, WPB, BM, MW, KM, OUT, MF>(a);
 #define X(NQ, EC, WPB, MW, KM) hex_mfma_case<NQ, EC, WPB, MW, KM>(a);
+#define XX(NQ, EC, WPB, MW, KM, XG) hex_mfma_case<NQ, EC, WPB, MW, KM, XG>(a);
     TUNE_CASES
 #else
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
