@@ -5,6 +5,8 @@
 #include "wave_launch.h"
 #include "wave_table.h"
 
+#include <cstdlib>
+
 namespace sf
 {
 
@@ -192,6 +194,24 @@ template <int NQ> static int go_f32(const HexArgsT<float> &a, hipStream_t s)
         hex_nq2_stream_f32_kernel<<<(unsigned)blocks, 256, 0, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
+    }
+    if constexpr (NQ >= 12)
+    {
+        // fp32 matrix-core kernel (hex_mfma_kernel, T = float: v_mfma_f32_16x16x4_f32) from nq = 13, where it is ahead of
+        // the vector kernel (tools/experiments/f32_hex_cfg.py, profiles/r03/f32_hex_mfma_configurations.log; 131 072
+        // elements, fraction of the fp32 HBM roofline, vector kernel in brackets): 13 0.594 (0.518)  14 0.590 (0.552)
+        // 15 0.676 (0.524)  16 0.705 (0.549); nq = 12 stays on the vector kernel (0.605 against 0.508).
+        // SF_F32_HEX_CFG is a development knob (0: vector kernel).
+        constexpr int best = NQ == 12 ? 0 : (NQ <= 14 ? 2 : 1);
+        static const int cfg = getenv("SF_F32_HEX_CFG") ? atoi(getenv("SF_F32_HEX_CFG")) : best;
+        switch (cfg)
+        {
+        case 1: return launch_hex_mfma<NQ, 1, 1, 1, 1, 64, float>(a, s);
+        case 2: return launch_hex_mfma<NQ, 1, 1, 2, 1, 64, float>(a, s);
+        case 3: return launch_hex_mfma<NQ, 1, 2, 2, 1, 64, float>(a, s);
+        case 4: return launch_hex_mfma<NQ, 2, 1, 1, 1, 64, float>(a, s);
+        default: break;
+        }
     }
     using C = HexCfgF32<NQ>;
     return launch_hex_wave<NQ, C::EC, C::WPB, C::BM, C::MW, C::KM, C::OUT, C::MF, float>(a, s);

@@ -304,11 +304,14 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma_kernel(
 // is assembled in LDS in final layout and leaves as one flat 16-byte-per-lane stream.
 // Padding (p, q, r, i, j, k beyond nm / nq) always meets a zero basis entry and clamped, finite data.
 // ================================================================================================
-template <int NQ, int EC> struct HexMfmaGeom
+template <int NQ, int EC, typename T = double> struct HexMfmaGeom
 {
+    static constexpr int VW  = 16 / (int)sizeof(T);
     static constexpr int NM  = NQ - 1;
     static constexpr int NMT = NM * NM * NM, NQ2 = NQ * NQ, NQT = NQ * NQ * NQ;
-    static constexpr int QP  = (NM + 3) / 4 * 4;        // padded q extent
+    // padded q extent.  fp64: a multiple of 4 (a D register holds four CONSECUTIVE rows).  fp32: 16 -- its D registers hold
+    // rows 4g + reg, so a register is one k-step of sweep 2 only when a whole 16-row tile belongs to one r
+    static constexpr int QP  = sizeof(T) == 8 ? (NM + 3) / 4 * 4 : 16;
     static constexpr int M1  = NM * QP;                 // rows of sweep 1
     static constexpr int MT1 = cdiv(M1, 16);
     static constexpr int KS1 = cdiv(NM, 4);             // p steps
@@ -318,10 +321,10 @@ template <int NQ, int EC> struct HexMfmaGeom
     static constexpr int S   = NM + ((6 - NM % 4) % 4); // input row stride, S % 4 == 2
     static constexpr int W2S = (NQ2 + 15) / 32 * 32 + 16; // W2 row stride, = 16 mod 32, >= NQ2
     static constexpr int IN_DBL = EC * NMT;
-    static constexpr bool VEC2  = (IN_DBL % 2) == 0;
-    static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / 2, kWave) : cdiv(IN_DBL, kWave);
+    static constexpr bool VEC2  = (IN_DBL % VW) == 0;
+    static constexpr int NLD    = VEC2 ? cdiv(IN_DBL / VW, kWave) : cdiv(IN_DBL, kWave);
     static constexpr int E0      = NM * NM * S > NM * W2S ? NM * NM * S : NM * W2S;
-    static constexpr int ESTRIDE = ((E0 > NQT ? E0 : NQT) + 1) & ~1; // per-element LDS region
+    static constexpr int ESTRIDE = ((E0 > NQT ? E0 : NQT) + VW - 1) / VW * VW; // per-element LDS region
     static constexpr int SLAB    = EC * ESTRIDE;
     static_assert(NQ <= 16, "one 16-wide tile per direction");
     static_assert(S % 4 == 2 && W2S % 32 == 16 && W2S >= NQ2, "LDS strides");
@@ -339,24 +342,29 @@ template <int NQ, int EC> struct HexMfmaGeom
     }
 };
 
-template <int NQ, int EC, int WPB> constexpr size_t hex_mfma_lds_bytes()
+template <int NQ, int EC, int WPB, typename T = double> constexpr size_t hex_mfma_lds_bytes()
 {
-    return sizeof(double) * (size_t)WPB * HexMfmaGeom<NQ, EC>::SLAB;
+    return sizeof(T) * (size_t)WPB * HexMfmaGeom<NQ, EC, T>::SLAB;
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
+template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0, typename T = double>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
-    const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
-    const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt)
+    const T *__restrict__ b0, const T *__restrict__ b1, const T *__restrict__ b2,
+    const T *__restrict__ in, T *__restrict__ out, uint64_t nelmt)
 {
-    using G          = HexMfmaGeom<NQ, EC>;
+    using G          = HexMfmaGeom<NQ, EC, T>;
+    using Op         = MfmaOp<T>;
+    using acc_t      = typename Op::acc_t;
+    using V          = typename VecOf<T>::type;
+    constexpr int VW = G::VW;
     constexpr int NM = G::NM, QP = G::QP, NQ2 = G::NQ2;
 
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_hexmfma[];
+    T *lds = reinterpret_cast<T *>(lds_raw_hexmfma);
     const int lane = threadIdx.x & (kWave - 1);
     const int wib  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int a = lane & 15, g = lane >> 4;
-    double *slab = lds + wib * G::SLAB;
+    T *slab = lds + wib * G::SLAB;
 
     const uint64_t nchunk = (nelmt + EC - 1) / EC;
     const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
@@ -364,24 +372,24 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
         return;
 
     // basis operands (zero outside nm x nq)
-    double opB0[G::KS1], opB1[G::KS2], opB2[G::KS3];
+    T opB0[G::KS1], opB1[G::KS2], opB2[G::KS3];
 #pragma unroll
     for (int ks = 0; ks < G::KS1; ++ks)
     {
         const int p = ks * 4 + g;
-        opB0[ks]    = (p < NM && a < NQ) ? b0[p * NQ + a] : 0.0; // B[k = p][col = i = a]
+        opB0[ks]    = (p < NM && a < NQ) ? b0[p * NQ + a] : T(0); // B[k = p][col = i = a]
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS2; ++ks)
     {
-        const int q = ks * 4 + g;
-        opB1[ks]    = (q < NM && a < NQ) ? b1[q * NQ + a] : 0.0; // A[row = j = a][k = q]
+        const int q = Op::drow(g, ks); // the q lane group g contributes to q step ks: row of D register ks of a W1 tile
+        opB1[ks]    = (q < NM && a < NQ) ? b1[q * NQ + a] : T(0); // A[row = j = a][k = q]
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS3; ++ks)
     {
         const int r = ks * 4 + g;
-        opB2[ks]    = (r < NM && a < NQ) ? b2[r * NQ + a] : 0.0; // A[row = k = a][k = r]
+        opB2[ks]    = (r < NM && a < NQ) ? b2[r * NQ + a] : T(0); // A[row = k = a][k = r]
     }
     // sweep-1 A gather: row R = 16t + a -> (r, q), clamped into the element
     int arow[G::MT1];
@@ -395,9 +403,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
         arow[t] = (r * NM + q) * G::S;
     }
 
-    using GW = WaveGeom<NQ, EC, 3>;
+    using GW = WaveGeom<NQ, EC, 3, T>;
     static_assert(GW::NLD == G::NLD && GW::IN_DBL == G::IN_DBL, "geometry mismatch");
-    double2_t st[G::NLD];
+    V st[G::NLD];
     // odd scalars per chunk (one element of an even order): the chunk base is only 8-byte aligned -> word-grid load
     auto fetch = [&](uint64_t cc) {
         if constexpr (G::VEC2)
@@ -405,8 +413,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
         else
         {
             const uint64_t lft = nelmt - cc * EC;
-            chunk_load_any_f64<G::IN_DBL>(st, in + cc * G::IN_DBL, lane,
-                                          lft >= EC ? G::IN_DBL : (int)lft * G::NMT);
+            chunk_load_any<G::IN_DBL, G::NLD, T>(st, in + cc * G::IN_DBL, lane,
+                                                 lft >= EC ? G::IN_DBL : (int)lft * G::NMT);
         }
     };
     fetch(it.first);
@@ -424,23 +432,23 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
             const int v = k * kWave + lane;
             if constexpr (G::VEC2)
             {
-                if ((k + 1) * kWave <= G::IN_DBL / 2 || v < G::IN_DBL / 2)
+                if ((k + 1) * kWave <= G::IN_DBL / VW || v < G::IN_DBL / VW)
                 {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < VW; ++h)
                     {
-                        const int f = 2 * v + h, row = f / NM, e = row / (NM * NM);
+                        const int f = VW * v + h, row = f / NM, e = row / (NM * NM);
                         slab[e * G::ESTRIDE + (row - e * NM * NM) * G::S + (f - row * NM)] = st[k][h];
                     }
                 }
             }
-            else if (k < word_grid_regs<G::IN_DBL, double>())
+            else if (k < word_grid_regs<G::IN_DBL, T>())
             {
-                const int a0 = line_offset_f64(in + c * G::IN_DBL);
+                const int a0 = line_offset<T>(in + c * G::IN_DBL);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < VW; ++h)
                 {
-                    const int f = 2 * v - a0 + h;
+                    const int f = VW * v - a0 + h;
                     if (f >= 0 && f < G::IN_DBL)
                     {
                         const int row = f / NM, e = row / (NM * NM);
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
 #pragma unroll 1
         for (int e = 0; e < evalid; ++e)
         {
-            double *img = slab + e * G::ESTRIDE;
+            T *img = slab + e * G::ESTRIDE;
             // ---- sweeps 1 and 2, fused tile by tile ------------------------------------------------------------
             // Sweep 1 produces one 16-row tile of W1 at a time; its four row groups are consumed at once as k-steps of
             // sweep 2 (tile t, group gr holds rows R0 = 16t + 4gr .. +3 = four consecutive q of r = R0 / QP), so only ONE
@@ -464,17 +472,17 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
             // scratch spill at nq = 16).  W2[r] goes to its LDS row [r][pos = j*NQ + i] as soon as (a) its last q group
             // is in and (b) every input row that LDS row overlaps has been gathered (w2_store_tile): q and r stay in
             // ascending order, so the sums are the unfused kernel's bit for bit.
-            double4_t w2[NM];
+            acc_t w2[NM];
 #pragma unroll
             for (int t = 0; t < G::MT1; ++t)
             {
-                double4_t w1t = double4_t{0.0, 0.0, 0.0, 0.0};
+                acc_t w1t = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
                 for (int ks = 0; ks < G::KS1; ++ks)
                 {
                     const int p  = ks * 4 + g;
                     const int pc = p < NM ? p : NM - 1;
-                    w1t = __builtin_amdgcn_mfma_f64_16x16x4f64(img[arow[t] + pc], opB0[ks], w1t, 0, 0, 0);
+                    w1t = Op::mma(img[arow[t] + pc], opB0[ks], w1t);
                 }
 #pragma unroll
                 for (int gr = 0; gr < 4; ++gr)
@@ -484,11 +492,11 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                     {
                         const int r = R0 / QP, qs = (R0 % QP) / 4;
                         if (qs == 0)
-                            w2[r] = double4_t{0.0, 0.0, 0.0, 0.0};
-                        w2[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB1[qs], w1t[gr], w2[r], 0, 0, 0);
+                            w2[r] = acc_t{T(0), T(0), T(0), T(0)};
+                        w2[r] = Op::mma(opB1[qs], w1t[gr], w2[r]);
                     }
                 }
-                // W2 rows that may leave now; lane (g,a), register r4 holds j = g + 4*r4, i = a
+                // W2 rows that may leave now; lane (g,a), register r4 holds j = drow(g, r4), i = a
                 bool any = false;
 #pragma unroll
                 for (int r = 0; r < NM; ++r)
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
 #pragma unroll
                             for (int r4 = 0; r4 < 4; ++r4)
                             {
-                                const int j = g + 4 * r4;
+                                const int j = Op::drow(g, r4);
                                 if (j < NQ && a < NQ)
                                     img[r * G::W2S + j * NQ + a] = w2[r][r4];
                             }
@@ -512,10 +520,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                 }
             }
             // ---- sweep 3 ------------------------------------------------------------------------
-            double4_t o[G::CB];
+            acc_t o[G::CB];
 #pragma unroll
             for (int cb = 0; cb < G::CB; ++cb)
-                o[cb] = double4_t{0.0, 0.0, 0.0, 0.0};
+                o[cb] = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int rs = 0; rs < G::KS3; ++rs)
             {
@@ -527,8 +535,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
                     int pos = cb * 16 + a;
                     if ((cb + 1) * 16 > NQ2)
                         pos = pos < NQ2 ? pos : NQ2 - 1;
-                    o[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(opB2[rs], img[rc * G::W2S + pos], o[cb], 0,
-                                                                 0, 0);
+                    o[cb] = Op::mma(opB2[rs], img[rc * G::W2S + pos], o[cb]);
                 }
             }
             // ---- Out image in LDS (final layout), then a flat stream --------------------------------------
@@ -538,13 +545,13 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma_kernel(
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
                 {
-                    const int k = g + 4 * r4, pos = cb * 16 + a;
+                    const int k = Op::drow(g, r4), pos = cb * 16 + a;
                     if (k < NQ && pos < NQ2)
                         img[k * NQ2 + pos] = o[cb][r4];
                 }
             wave_lds_fence();
-            double *oe      = out + (c * EC + e) * (uint64_t)G::NQT;
-            flush_any_f64<G::NQT>(img, oe, G::NQT, lane);
+            T *oe = out + (c * EC + e) * (uint64_t)G::NQT;
+            flush_any<G::NQT, T>(img, oe, G::NQT, lane);
             wave_lds_fence();
         }
         wave_lds_fence(); // slab is rewritten by the next chunk's staging

@@ -175,12 +175,12 @@ inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
         return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB, PEEL>(a, s);
 }
 
-template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0>
-inline int launch_hex_mfma(const HexArgs &a, hipStream_t s, int grid_override = 0)
+template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0, typename T = double>
+inline int launch_hex_mfma(const HexArgsT<T> &a, hipStream_t s, int grid_override = 0)
 {
     static OccCache cache = {};
-    auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP, XG>;
-    constexpr size_t lds = hex_mfma_lds_bytes<NQ, EC, WPB>();
+    auto kern            = hex_mfma_kernel<NQ, EC, WPB, MINW, KMAP, XG, T>;
+    constexpr size_t lds = hex_mfma_lds_bytes<NQ, EC, WPB, T>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)
         return SF_OK;

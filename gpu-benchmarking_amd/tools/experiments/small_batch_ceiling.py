@@ -7,7 +7,7 @@ the BwdTrans launches themselves.  Usage: python3 tools/small_batch_ceiling.py""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

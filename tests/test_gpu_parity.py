@@ -561,21 +561,23 @@ def test_runtime_arbitrary_orders(sf, oracle, torch_mod):
 
 
 def test_fp32_beyond_the_fp64_wave_tables(sf, oracle, torch_mod):
-    """T = float (a template parameter of every reference kernel, benchmark05/benchmark05.cc:291): hex nq 12..16 and
-    quad nq 25..31 run the fp32 wave kernel (fp64 uses the matrix cores there); above that the generic kernels."""
+    """T = float (a template parameter of every reference kernel, benchmark05/benchmark05.cc:291): hex nq 12 runs the
+    fp32 wave kernel, 13..16 the fp32 matrix-core kernel (v_mfma_f32_16x16x4_f32, hex_mfma_kernel with T = float), quad
+    nq 25..32 the fp32 matrix-core kernel (quad_mfma_kernel with T = float); above that the generic kernels.  The fp32
+    matrix instruction sums the q of a 16-row tile in the order r, r+4, r+8, r+12 (its D register map): tolerance 2e-5."""
     f32 = torch_mod.float32
     for nq in list(range(12, 18)) + [20, 22]:
         nm = nq - 1
-        for nelmt in (1, 2, 7, 65, 130) if nq <= 16 else (5,):
+        for nelmt in (1, 2, 7, 65, 130, 1000) if nq <= 16 else (5,):
             bs = [sf.fill_random(nm * nq, 31 + d, dtype=f32) for d in range(3)]
             x = sf.fill_random(nelmt * nm ** 3, nelmt, dtype=f32)
             out = sf.bwdtrans_hex((nq,) * 3, *bs, x)
             ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *[_np(b).astype(np.float64) for b in bs],
                                       _np(x).astype(np.float64))
             assert oracle.rel_err(_np(out).astype(np.float64), ref) <= TOL32, (nq, nelmt)
-    for nq in list(range(25, 32)) + [33, 48]:
+    for nq in list(range(25, 33)) + [33, 48]:
         nm = nq - 1
-        for nelmt in (1, 2, 3, 64, 999):
+        for nelmt in (1, 2, 3, 5, 64, 999, 4099):
             bs = [sf.fill_random(nm * nq, 41 + d, dtype=f32) for d in range(2)]
             x = sf.fill_random(nelmt * nm * nm, nelmt, dtype=f32)
             out = sf.bwdtrans_quad((nq, nq), *bs, x)
