@@ -83,7 +83,19 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // for the padded step -- which removes 1/TQ (12-14 %) of the matrix instructions; the chip sustains a fixed rate of
 // issued fp64 matrix work next to the memory stream, so fewer issued products is what moves these orders.
 // The sums stay in ascending order of p and q (matrix steps first, the peeled remainder last).
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true>
+// SPLIT (EB = 2 with an ODD number of i tiles, nq 25..28 and 17..20): an instruction holds two elements x two i tiles, so
+// the last, unpaired i tile used to occupy a whole instruction with two of its four blocks idle -- 12.5 % of all
+// products at seven tiles.  Its two spare blocks now take every other q tile: block (e, h) computes W[q tile 2u + h][last
+// i tile] in step 1 and the partial sum over the q tiles of parity h in step 2; the two partial sums meet through one
+// lane swizzle (lanes l and l ^ 4) per output tile.  The unpaired tile then costs half an instruction slot per product:
+// 175 instead of 196 instructions per element at nq = 28.  Its sums run over the even q tiles, then the odd ones.
+// MEASURED (profiles/r03/tune_mfma4_2[5-8]_split_unpaired_tile.log): 10.7 % fewer matrix instructions change NOTHING on
+// the persistent configurations AUTO runs (nq 28: 0.648 with, 0.656 without) and give +3 % on one-chunk workgroups
+// (0.569 against 0.551) -- together with the peeled k remainder (-12..14 % instructions, +0..3 %) and the all-zero-data
+// run (+3..5 %, tools/experiments/zero_data_clock.py) this rules the matrix pipe out as what bounds nq 25..31.  Off by
+// default: AUTO's results stay bit-identical to the generic kernel's.
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true,
+          bool SPLIT = false>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr)
@@ -93,6 +105,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     constexpr int NM = G::NM, IB = G::IB, TQ = G::TQ, TI = G::TI, TG = G::TG, BS = G::BS;
     constexpr int RQ = (PEEL && (NM % 4 == 1 || NM % 4 == 2)) ? NM % 4 : 0; // p / q values contracted on the vector pipe
     constexpr int KQ = RQ ? NM / 4 : TQ;                                     // 4-wide k steps on the matrix pipe
+    constexpr bool ODD = SPLIT && IB == 2 && (TI % 2 == 1); // the last i tile has no partner
+    constexpr int TGF  = ODD ? TI / 2 : TG;                 // instructions per (q tile, p step) that hold IB paired i tiles
+    constexpr int TS   = TI - 1;                            // the unpaired i tile
+    constexpr int TQH = (TQ + 1) / 2, KQH = (KQ + 1) / 2;   // q tiles / matrix q steps per half
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bl0 = lds, *bl1 = SHB ? lds : lds + G::NBAS;
@@ -227,6 +243,10 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
 #pragma unroll
             for (int ig = 0; ig < TG; ++ig)
                 w[tq][ig] = 0.0;
+        double ws[ODD ? TQH : 1]; // W[q tile 2u + ib][unpaired i tile]
+#pragma unroll
+        for (int u = 0; u < (ODD ? TQH : 1); ++u)
+            ws[u] = 0.0;
         {
             int arow[TQ];
 #pragma unroll
@@ -239,6 +259,18 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             // operands of p step tp+1 are requested before the products of step tp are issued: an LDS read takes longer
             // than the few 16-cycle products that consume it, and hipcc does not move it up by itself
             double a1[2][TQ], bt[2][TG];
+            // the unpaired i tile: block (e, h = ib) takes the q tiles 2u + h
+            int arows[ODD ? TQH : 1];
+            double a1s[2][ODD ? TQH : 1], bts[2];
+            if constexpr (ODD)
+            {
+#pragma unroll
+                for (int u = 0; u < TQH; ++u)
+                {
+                    const int q = 4 * (2 * u + ib) + lo;
+                    arows[u]    = e * G::ESTR + (q < NM ? q : NM - 1) * G::S;
+                }
+            }
             auto request = [&](int buf, int tp) {
                 const int p  = 4 * tp + hi;
                 const int pc = p < NM ? p : NM - 1;
@@ -246,8 +278,15 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                 for (int tq = 0; tq < TQ; ++tq)
                     a1[buf][tq] = slab[arow[tq] + pc];
 #pragma unroll
-                for (int ig = 0; ig < TG; ++ig)
+                for (int ig = 0; ig < TGF; ++ig)
                     bt[buf][ig] = btile[4 * tp * BS + 4 * IB * ig];
+                if constexpr (ODD)
+                {
+#pragma unroll
+                    for (int u = 0; u < TQH; ++u)
+                        a1s[buf][u] = slab[arows[u] + pc];
+                    bts[buf] = bl0[(4 * tp + hi) * BS + 4 * TS + lo];
+                }
             };
             request(0, 0);
 #pragma unroll
@@ -257,10 +296,16 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                     request((tp + 1) & 1, tp + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ig = 0; ig < TG; ++ig)
+                for (int ig = 0; ig < TGF; ++ig)
 #pragma unroll
                     for (int tq = 0; tq < TQ; ++tq)
                         w[tq][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[tp & 1][tq], bt[tp & 1][ig], w[tq][ig], 0, 0, 0);
+                if constexpr (ODD)
+                {
+#pragma unroll
+                    for (int u = 0; u < TQH; ++u)
+                        ws[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1s[tp & 1][u], bts[tp & 1], ws[u], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (RQ > 0)
@@ -278,16 +323,30 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                         ain[d][tq]  = slab[e * G::ESTR + (q < NM ? q : NM - 1) * G::S + 4 * KQ + d];
                     }
 #pragma unroll
-                    for (int ig = 0; ig < TG; ++ig)
+                    for (int ig = 0; ig < TGF; ++ig)
                         bin[d][ig] = bl0[(4 * KQ + d) * BS + 4 * (IB * ig + ib) + lo];
                 }
 #pragma unroll
                 for (int d = 0; d < RQ; ++d)
 #pragma unroll
-                    for (int ig = 0; ig < TG; ++ig)
+                    for (int ig = 0; ig < TGF; ++ig)
 #pragma unroll
                         for (int tq = 0; tq < TQ; ++tq)
                             w[tq][ig] = __builtin_fma(ain[d][tq], bin[d][ig], w[tq][ig]);
+                if constexpr (ODD)
+                {
+#pragma unroll
+                    for (int d = 0; d < RQ; ++d)
+                    {
+                        const double bs1 = bl0[(4 * KQ + d) * BS + 4 * TS + lo];
+#pragma unroll
+                        for (int u = 0; u < TQH; ++u)
+                        {
+                            const int q = 4 * (2 * u + ib) + hi;
+                            ws[u] = __builtin_fma(slab[e * G::ESTR + (q < NM ? q : NM - 1) * G::S + 4 * KQ + d], bs1, ws[u]);
+                        }
+                    }
+                }
             }
         }
         // peeled q: row q = 4 KQ + d of W sits in w[TQ - 1] on the lanes with hi == d; every lane needs it for its own
@@ -298,7 +357,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
 #pragma unroll
             for (int d = 0; d < RQ; ++d)
 #pragma unroll
-                for (int ig = 0; ig < TG; ++ig)
+                for (int ig = 0; ig < TGF; ++ig)
                 {
                     const int src = 4 * (16 * d + (lane & 15));
                     const double v = w[TQ - 1][ig];
@@ -306,6 +365,20 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                     const int vhi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
                     wf[d][ig]     = __hiloint2double(vhi, vlo);
                 }
+        }
+        // the same for the unpaired tile: q tile TQ - 1 sits in ws[(TQ - 1) / 2] of the blocks with ib == (TQ - 1) % 2
+        double wfs[RQ > 0 ? RQ : 1];
+        if constexpr (RQ > 0 && ODD)
+        {
+#pragma unroll
+            for (int d = 0; d < RQ; ++d)
+            {
+                const int src = 4 * (16 * d + 4 * (2 * e + (TQ - 1) % 2) + lo);
+                const double v = ws[(TQ - 1) / 2];
+                const int vlo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+                const int vhi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+                wfs[d]        = __hiloint2double(vhi, vlo);
+            }
         }
         wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
 
@@ -323,11 +396,26 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                     for (int ig = 0; ig < TG; ++ig)
                         o[t][ig] = 0.0;
                 double a2[2][GJ];
+                // unpaired i tile: os[t] = partial sum over the q tiles 2u + ib of Out[j tile j0 + t][i tile TS]
+                double os[ODD ? GJ : 1], a2s[2][ODD ? GJ : 1];
+#pragma unroll
+                for (int t = 0; t < (ODD ? GJ : 1); ++t)
+                    os[t] = 0.0;
                 auto request = [&](int buf, int tq) {
 #pragma unroll
                     for (int t = 0; t < GJ; ++t)
                         if (j0 + t < TI)
                             a2[buf][t] = atile[4 * tq * BS + 4 * (j0 + t)];
+                };
+                auto request_s = [&](int buf, int u) {
+                    const int qt = 2 * u + ib; // this block's q tile; beyond the matrix steps it contributes nothing
+#pragma unroll
+                    for (int t = 0; t < GJ; ++t)
+                        if (j0 + t < TI)
+                        {
+                            const double v = atile[4 * (qt < KQ ? qt : KQ - 1) * BS + 4 * (j0 + t)];
+                            a2s[buf][t]    = qt < KQ ? v : 0.0;
+                        }
                 };
                 request(0, 0);
 #pragma unroll
@@ -342,10 +430,26 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                         if (j0 + t >= TI)
                             continue;
 #pragma unroll
-                        for (int ig = 0; ig < TG; ++ig)
+                        for (int ig = 0; ig < TGF; ++ig)
                             o[t][ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[tq & 1][t], w[tq][ig], o[t][ig], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (ODD)
+                {
+                    request_s(0, 0);
+#pragma unroll
+                    for (int u = 0; u < KQH; ++u)
+                    {
+                        if (u + 1 < KQH)
+                            request_s((u + 1) & 1, u + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < GJ; ++t)
+                            if (j0 + t < TI)
+                                os[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2s[u & 1][t], ws[u], os[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if constexpr (RQ > 0)
                 {
@@ -359,19 +463,38 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                                 continue;
                             const double bq = bl1[(4 * KQ + d) * BS + 4 * (j0 + t) + hi];
 #pragma unroll
-                            for (int ig = 0; ig < TG; ++ig)
+                            for (int ig = 0; ig < TGF; ++ig)
                                 o[t][ig] = __builtin_fma(bq, wf[d][ig], o[t][ig]);
+                            if constexpr (ODD) // once: on the half that holds the even q tiles
+                                os[t] = __builtin_fma(ib == 0 ? bq : 0.0, wfs[d], os[t]);
                         }
                 }
 #pragma unroll
                 for (int t = 0; t < GJ; ++t)
 #pragma unroll
-                    for (int ig = 0; ig < TG; ++ig)
+                    for (int ig = 0; ig < TGF; ++ig)
                     {
                         const int tj = j0 + t;
                         if (tj < TI && 4 * tj + hi < NQ && 4 * (IB * ig + ib) + lo < NQ)
                             oimg[4 * tj * NQ + 4 * IB * ig] = o[t][ig];
                     }
+                if constexpr (ODD)
+                {
+                    // the two halves of a block pair (lanes l and l ^ 4) hold the even- and the odd-q-tile partial sums
+#pragma unroll
+                    for (int t = 0; t < GJ; ++t)
+                    {
+                        const int tj = j0 + t;
+                        if (tj >= TI)
+                            continue;
+                        const double mine = os[t];
+                        const int plo = __builtin_amdgcn_ds_swizzle(__double2loint(mine), 0x101F); // lane ^ 4
+                        const int phi = __builtin_amdgcn_ds_swizzle(__double2hiint(mine), 0x101F);
+                        const double sum = mine + __hiloint2double(phi, plo);
+                        if (ib == 0 && 4 * tj + hi < NQ && 4 * TS + lo < NQ)
+                            slab[e * G::NQT + (4 * tj + hi) * NQ + 4 * TS + lo] = sum;
+                    }
+                }
             }
         }
         wave_lds_fence();

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void quad_nq2_stream_f32_kernel(const float *_
 
 // fp32 orders from here on run the matrix-core kernel: its 16-wide tiles are (nearly) full there, and the vector kernel
 // is issue-bound (0.41-0.52 of the roofline at nq 25..32, profiles/r02/sweep_auto_f32.log)
-constexpr int kQuadF32MfmaFrom = 25;
+constexpr int kQuadF32MfmaFrom = 25; // below, the vector kernel is ahead at every configuration (0.55-0.73 against 0.35-0.55)
 
 template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
 {
@@ -101,10 +101,11 @@ template <int NQ> static int go_f32(const QuadArgsT<float> &a, hipStream_t s)
     {
         // v_mfma_f32_16x16x4_f32 (bwdtrans_mfma.h, T = float): two-element chunks, LDS-staged line-aligned output where the
         // rows are not whole lines, two waves per SIMD, XCD runs
-        // per order the best of tools/experiments/f32_mfma_cfg.sh (profiles/r03/f32_mfma_configurations.log; fraction of
-        // the fp32 HBM roofline at 1 Mi elements, vector kernel in brackets): 25 0.542 (0.506)  26 0.529 (0.509)
-        // 27 0.564 (0.496)  28 0.570 (0.514)  29 0.609 (0.517)  30 0.571 (0.512)  31 0.636 (0.505)  32 0.641 (0.416)
-        constexpr int best = (NQ == 25 || NQ == 26) ? 3 : ((NQ == 28 || NQ == 32) ? 2 : (NQ == 30 ? 4 : (NQ == 27 ? 0 : 1)));
+        // per order the best of tools/experiments/f32_mfma_cfg.sh over two boxes (profiles/r03/f32_mfma_configurations*.log;
+        // fraction of the fp32 HBM roofline at 1 Mi elements, vector kernel in brackets): 25 0.54-0.57 (0.51)
+        // 26 0.53-0.54 (0.51)  27 0.56-0.57 (0.50)  28 0.57 (0.52)  29 0.60-0.61 (0.52)  30 0.57-0.58 (0.52)
+        // 31 0.61-0.62 (0.51)  32 0.64 (0.42); at nq 17..24 the vector kernel stays ahead (second log)
+        constexpr int best = NQ == 25 ? 3 : ((NQ == 28 || NQ == 32) ? 2 : ((NQ == 26 || NQ == 30 || NQ == 31) ? 4 : (NQ == 27 ? 0 : 1)));
         static const int cfg = getenv("SF_F32_MFMA_CFG") ? atoi(getenv("SF_F32_MFMA_CFG")) : best; // development knob
         switch (cfg)
         {

@@ -121,11 +121,11 @@ inline int launch_quad_mfma(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB, bool PEEL = true>
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB, bool PEEL = true, bool SPLIT = false>
 inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 {
     static OccCache cache = {};
-    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB, PEEL>;
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB, PEEL, SPLIT>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, SHB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     static_assert(DYNB == 0 || KMAP == 0, "the batch counter feeds a persistent grid");
@@ -144,7 +144,7 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         // same kernel with a fixed share per wave
         unsigned long long *ctr = nullptr;
         if (counter_acquire(s, &ctr) != SF_OK)
-            return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0, PEEL>(a, s);
+            return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0, PEEL, SPLIT>(a, s);
         // zeroed by a one-thread kernel, not a memset: under stream capture a memset node on a pointer INSIDE an
         // allocation did not zero the counter on ROCm 7.2 (the replayed grid then saw a stale ticket and exited)
         counter_reset_kernel<<<1, 1, 0, s>>>(ctr);
@@ -162,17 +162,17 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 
 // SHBONLY: the configuration only fits the LDS with one basis copy (b0 == b1)
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHBONLY = false, int DYNB = 0,
-          bool PEEL = true>
+          bool PEEL = true, bool SPLIT = false>
 inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
 {
     if (a.nelmt == 0)
         return SF_OK;
     if (a.b0 == a.b1)
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true, DYNB, PEEL>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true, DYNB, PEEL, SPLIT>(a, s);
     if constexpr (SHBONLY)
         return SF_ENOTBUILT;
     else
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB, PEEL>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB, PEEL, SPLIT>(a, s);
 }
 
 template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0, typename T = double>

@@ -22,8 +22,13 @@ N=1048576
 for nq in 2 3 4 5 6 7 8 9 10; do
   run hex_${nq}_$N "$here/bin/benchmark05" $nq $nq $nq --nelmt $N --no-baselines --data random || exit 1
 done
-for nq in 2 4 6 8 10 12 14 16 20 24 28 32; do
+for nq in 2 4 6 8 10 12 14 16 20 24 26 28 30 32; do
   run quad_${nq}_$N "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random || exit 1
+done
+# anisotropic extents (round 3): the compile-time triples of csrc/bwdtrans_wave3.h and one run-time-extent shape
+for shape in "8 8 4" "4 8 6" "10 6 8" "3 5 4"; do
+  set -- $shape
+  run hex_$1x$2x$3_$N "$here/bin/benchmark05" $1 $2 $3 --nelmt $N --no-baselines --data random || exit 1
 done
 run hex_8_1250000 "$here/bin/benchmark05" 8 8 8 --nelmt 1250000 --no-baselines --data random || exit 1
 run hex_8_10000000 "$here/bin/benchmark05" 8 8 8 --nelmt 10000000 --no-baselines --data random || exit 1

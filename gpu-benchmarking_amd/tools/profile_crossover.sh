@@ -44,4 +44,10 @@ done
 for nq in 16 20 22 24 26 28 30 32; do
   run quad_nq${nq}_mfma4 "$here/bin/benchmark04" $nq $nq --nelmt $N --no-baselines --data random --variant mfma4 || exit 1
 done
+# round 3: anisotropic extents through SF_VARIANT_AUTO (compile-time triples, bwdtrans_wave3.h) and the run-time-extent kernel
+for shape in "8 8 4" "4 8 6" "10 6 8"; do
+  set -- $shape
+  run hex_$1x$2x$3_auto "$here/bin/benchmark05" $1 $2 $3 --nelmt $N --no-baselines --data random --variant auto || exit 1
+  run hex_$1x$2x$3_wave-rt "$here/bin/benchmark05" $1 $2 $3 --nelmt $N --no-baselines --data random --variant wave-rt || exit 1
+done
 echo all-done

@@ -11,12 +11,12 @@ what="${2:-all}"
 mkdir -p "$out/benchmark01" "$out/benchmark02" "$out/benchmark03" "$out/benchmark04" "$out/benchmark05"
 if [ "$what" = hex ] || [ "$what" = all ]; then
   for i in 2 3 4 5 6 7 8 9 10; do
-    echo "hex nq=$i"; "$here/bin/benchmark05" $i $i $i &> "$out/benchmark05/nq${i}x${i}x${i}.log"
+    echo "hex nq=$i"; "$here/bin/benchmark05" $i $i $i --json "$out/benchmark05/nq${i}x${i}x${i}.json" &> "$out/benchmark05/nq${i}x${i}x${i}.log"
   done
 fi
 if [ "$what" = quad ] || [ "$what" = all ]; then
-  for i in 2 4 6 8 10 12 14 16 20 24 28 32; do
-    echo "quad nq=$i"; "$here/bin/benchmark04" $i $i &> "$out/benchmark04/nq${i}x${i}.log"
+  for i in 2 4 6 8 10 12 14 16 20 24 26 28 30 32; do
+    echo "quad nq=$i"; "$here/bin/benchmark04" $i $i --json "$out/benchmark04/nq${i}x${i}.json" &> "$out/benchmark04/nq${i}x${i}.log"
   done
 fi
 if [ "$what" = misc ] || [ "$what" = all ]; then

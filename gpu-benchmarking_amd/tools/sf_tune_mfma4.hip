@@ -92,7 +92,8 @@ template <class F> static void run(const char *label, const QuadArgs &a, F launc
     std::fflush(stdout);
 }
 
-template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEEL = true> static void m4(const QuadArgs &a)
+template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEEL = true, bool SPLIT = false>
+static void m4(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
     if constexpr (mfma4_lds_bytes<NQ, EB, WPB, true>() <= 160 * 1024 && mfma4_lds_bytes<NQ, EB, WPB>() > 160 * 1024)
@@ -106,8 +107,8 @@ template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEE
     {
         char label[96];
         std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d dyn%d%s lds %zu", NQ, EB, WPB, MW, GJ, K,
-                      XG, DYNB, PEEL ? "" : " nopeel", mfma4_lds_bytes<NQ, EB, WPB>());
-        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB, PEEL>(a, 0); });
+                      XG, DYNB, PEEL ? (SPLIT ? " split" : "") : " nopeel", mfma4_lds_bytes<NQ, EB, WPB>());
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB, PEEL, SPLIT>(a, 0); });
     }
 }
 
@@ -145,6 +146,9 @@ int main(int argc, char **argv)
         m4<2, 4, 2, 4, 0, 0>(a);
         m4<2, 4, 2, 4, 0, 0, 4>(a);
         m4<2, 4, 2, 4, 0, 0, 4, false>(a); // the same without the peeled k remainder (differs at nm = 1, 2 mod 4 only)
+        m4<2, 4, 2, 4, 0, 0, 4, true, true>(a); // ... with the unpaired i tile's spare blocks splitting the q tiles (odd tile counts)
+        m4<2, 4, 2, 4, 1, 64, 0, true, true>(a);
+        m4<2, 4, 2, 4, 2, 64, 0, true, true>(a);
         m4<2, 4, 2, 4, 1, 64, 0, false>(a);
         m4<2, 4, 2, 4, 0, 0, 8>(a);
         m4<2, 8, 2, 4, 0, 0, 8>(a);
@@ -161,6 +165,11 @@ int main(int argc, char **argv)
         m4<2, 1, 2, 4, 1, 64>(a);
         m4<2, 3, 3, 4, 1, 64>(a);
         m4<2, 2, 2, 4, 2, 64>(a);
+        // three waves per SIMD by registers (<= 168 VGPRs): with one shared basis copy three four-wave workgroups fit
+        // the LDS up to nq = 26
+        m4<2, 4, 3, 4, 1, 64>(a);
+        m4<2, 4, 3, 4, 2, 64>(a);
+        m4<2, 4, 3, 2, 1, 64>(a);
     }
     return 0;
 }

@@ -13,14 +13,14 @@ import os
 import sys
 
 HBM_PEAK, FP64_PEAK = 8.0e12, 78.6e12
+KERNELS = ("wave_kernel", "wave3_kernel", "wave_rt_kernel", "mfma_kernel", "mfma4_kernel", "stream_kernel")
 
 
 def kernel_rows(path, key="wave_kernel"):
     rows = []
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(f))
-                 if "wave_kernel" in r["Kernel_Name"] or "mfma_kernel" in r["Kernel_Name"]
-                 or "mfma4_kernel" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"]]
+                 if any(k in r["Kernel_Name"] for k in KERNELS)]
     return rows
 
 
@@ -34,7 +34,7 @@ def counter_means(path):
 def kernel_time_ns(path):
     for f in glob.glob(os.path.join(path, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if any(k in r["Name"] for k in ("wave_kernel", "mfma_kernel", "mfma4_kernel", "stream_kernel")):
+            if any(k in r["Name"] for k in KERNELS):
                 return float(r["AverageNs"]), int(r["Calls"]), r["Name"].split("(")[0]
     return None, 0, ""
 

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-KERNELS = ("wave_kernel", "mfma_kernel", "mfma4_kernel", "stream_kernel", "block_kernel")
+KERNELS = ("wave_kernel", "wave3_kernel", "wave_rt_kernel", "mfma_kernel", "mfma4_kernel", "stream_kernel", "block_kernel")
 
 
 def upsert(rec, row):
     rows = [r for r in rec.setdefault("rows", [])
             if not (r.get("dim", 3) == row["dim"] and r["nq"] == row["nq"] and r["nelmt"] == row["nelmt"])]
     rows.append(row)
-    rec["rows"] = sorted(rows, key=lambda r: (r.get("dim", 3), r["nelmt"], r["nq"]))
+    rec["rows"] = sorted(rows, key=lambda r: (r.get("dim", 3), r["nelmt"], isinstance(r["nq"], list), str(r["nq"]).zfill(12)))
 
 
 def counter(path, name):
@@ -46,10 +46,12 @@ def main(root, rnd):
                    "collection time.")
     h = shard.kernel_source_hash(ROOT)
     for d in sorted(os.listdir(root)):
-        m = re.match(r"(hex|quad)_(\d+)_(\d+)$", d)
+        m = re.match(r"(hex|quad)_(\d+(?:x\d+)*)_(\d+)$", d)
         if not m or not os.path.isdir(os.path.join(root, d)):
             continue
-        dim, nq, nelmt = (3 if m.group(1) == "hex" else 2), int(m.group(2)), int(m.group(3))
+        dim, nelmt = (3 if m.group(1) == "hex" else 2), int(m.group(3))
+        ext = [int(v) for v in m.group(2).split("x")]          # one order, or anisotropic extents a x b x c
+        nq  = ext[0] if len(ext) == 1 else ext
         fetch, kern = counter(os.path.join(root, d, "fetch"), "FETCH_SIZE")
         write, _ = counter(os.path.join(root, d, "write"), "WRITE_SIZE")
         if not fetch or not write:
@@ -57,18 +59,22 @@ def main(root, rnd):
             continue
         # a batch above 2 x 524 288 elements at 3D nq = 7 / 8 is one library call = several dispatches
         # (csrc/wave_table.h hex_piece()): bytes per CALL = mean per dispatch x dispatches per call
-        per_call = shard.hex_dispatches_per_call(nq, nelmt) if dim == 3 else 1
+        per_call = shard.hex_dispatches_per_call(nq, nelmt) if (dim == 3 and len(ext) == 1) else 1
+        full = ext * dim if len(ext) == 1 else ext
+        nmt, nqt = 1, 1
+        for q in full:
+            nmt, nqt = nmt * (q - 1), nqt * q
         if len(fetch) % per_call or len(write) % per_call:
             print("dispatch count of", d, "is not a multiple of", per_call)
             continue
         rd, wr = 2048.0 * sum(fetch) / len(fetch) * per_call, 1024.0 * sum(write) / len(write) * per_call
-        alg = 8 * nelmt * ((nq - 1) ** dim + nq ** dim)
+        alg = 8 * nelmt * (nmt + nqt)
         row = {"dim": dim, "nq": nq, "nelmt": nelmt, "kernel": kern, "round": int(rnd), "dispatches": len(fetch),
                "dispatches_per_call": per_call,
                "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 4),
-               "read_over_algorithmic": round(rd / (8 * nelmt * (nq - 1) ** dim), 4),
-               "write_over_algorithmic": round(wr / (8 * nelmt * nq ** dim), 4), "kernel_source_hash": h}
+               "read_over_algorithmic": round(rd / (8 * nelmt * nmt), 4),
+               "write_over_algorithmic": round(wr / (8 * nelmt * nqt), 4), "kernel_source_hash": h}
         upsert(rec, row)
         print(f"{d:22s} {kern[:48]:48s} traffic {row['traffic_over_algorithmic']:.4f} x algorithmic "
               f"(reads {row['read_over_algorithmic']:.3f} x, writes {row['write_over_algorithmic']:.3f} x)")
