@@ -95,11 +95,25 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // run (+3..5 %, tools/experiments/zero_data_clock.py) this rules the matrix pipe out as what bounds nq 25..31.  Off by
 // default: AUTO's results stay bit-identical to the generic kernel's.
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true,
-          bool SPLIT = false>
+          bool SPLIT = false, bool STAMP = false>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
-    double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr)
+    double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr,
+    unsigned long long *stamps = nullptr)
 {
+    // STAMP (tools/sf_tune_mfma4 only; no product instantiation): shader-clock time per phase of the chunk loop, summed
+    // per wave into stamps[8 * wave + 0..5] (staging + next loads issued / step 1 / step 2 + output image / flush issued /
+    // wait for the next chunk / chunks).  The stamps go to a buffer of their own; no output value depends on them.
+    unsigned long long tphase[5] = {0, 0, 0, 0, 0}, tlast = 0, nch = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP)
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (k >= 0)
+                tphase[k] += now - tlast;
+            tlast = now;
+        }
+    };
     using G  = Mfma4Geom<NQ, EB>;
     using GW = WaveGeom<NQ, EB, 2>; // chunk_load / chunk_flush geometry (IN_DBL, NLD, OUT_DBL)
     constexpr int NM = G::NM, IB = G::IB, TQ = G::TQ, TI = G::TI, TG = G::TG, BS = G::BS;
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     {
         const uint64_t left = nelmt - c * EB;
         const int evalid    = left >= (uint64_t)EB ? EB : (int)left;
+        stamp(-1);
 
         // ---- chunk: staging registers -> LDS image (HBM layout: flat copy); then request the next chunk -----------------
         if constexpr (GW::VEC2)
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             chunk_fetch<GW, EB>(st, in, cn, nelmt, lane);
         }
 
+        stamp(0);
         // ---- step 1: W[q][i] = sum_p In[q][p] B0[p][i]; D = W[q on hi][i on lo] of block (e, ib) ---------------------
         double w[TQ][TG];
 #pragma unroll
@@ -381,6 +397,7 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             }
         }
         wave_lds_fence(); // every gather of the input image has completed: the slab becomes the output image
+        stamp(1);
 
         // ---- step 2: Out[j][i] = sum_q B1[q][j] W[q][i]; D = Out[j on hi][i on lo] ------------------------------------
         {
@@ -498,14 +515,29 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
             }
         }
         wave_lds_fence();
+        stamp(2);
         // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
         chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
         wave_lds_fence(); // the slab is rewritten by the next chunk's staging
+        stamp(3);
+        ++nch;
         if (cn == kNone)
             break;
         touch_staged(st); // counted wait for the next chunk here, not vmcnt(0) at the loop header
+        stamp(4);
         c  = cn;
         cn = cnn;
+    }
+    if constexpr (STAMP)
+    {
+        if (lane == 0 && stamps) // a slot per wave (atomics on one address would serialise half a million waves)
+        {
+            unsigned long long *mine = stamps + ((uint64_t)blockIdx.x * WPB + wib) * 8;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                mine[k] = tphase[k];
+            mine[5] = nch;
+        }
     }
 }
 

@@ -148,13 +148,13 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         // zeroed by a one-thread kernel, not a memset: under stream capture a memset node on a pointer INSIDE an
         // allocation did not zero the counter on ROCm 7.2 (the replayed grid then saw a stale ticket and exited)
         counter_reset_kernel<<<1, 1, 0, s>>>(ctr);
-        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr);
+        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr, nullptr);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
     }
     else
     {
-        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, nullptr);
+        kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, nullptr, nullptr);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
     }

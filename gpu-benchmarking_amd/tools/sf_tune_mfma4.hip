@@ -112,6 +112,53 @@ static void m4(const QuadArgs &a)
     }
 }
 
+// shader-clock time per phase of the chunk loop (quad_mfma4_kernel with STAMP): persistent grid fed by the batch counter,
+// or one chunk per wave
+template <int EB, int WPB, int MW, int K, int XG, int DYNB> static void phases(const QuadArgs &a)
+{
+    constexpr int NQ = TUNE_NQ;
+    auto kern        = quad_mfma4_kernel<NQ, EB, WPB, MW, 4, K, XG, true, DYNB, true, false, true>;
+    constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, true>();
+    if (lds > 48 * 1024)
+        CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = 0, cus = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, kWave * WPB, lds));
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    const uint64_t nchunk = (a.nelmt + EB - 1) / EB;
+    const uint64_t need   = (nchunk + (uint64_t)WPB * (K > 0 ? K : 1) - 1) / ((uint64_t)WPB * (K > 0 ? K : 1));
+    uint64_t grid         = (uint64_t)bpc * cus;
+    if (K != 0 || grid > need)
+        grid = need;
+    const size_t nslot = (size_t)grid * WPB * 8;
+    unsigned long long *dev, *ctr, host[8] = {};
+    CK(hipMalloc((void **)&dev, nslot * sizeof(unsigned long long)));
+    CK(hipMalloc((void **)&ctr, 64));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) // the last repetition is reported
+    {
+        CK(hipMemset(dev, 0, nslot * sizeof(unsigned long long)));
+        CK(hipMemset(ctr, 0, 64));
+        CK(hipEventRecord(g_e0, 0));
+        kern<<<(unsigned)grid, kWave * WPB, lds>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr, dev);
+        CK(hipEventRecord(g_e1, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+    }
+    std::vector<unsigned long long> all(nslot);
+    CK(hipMemcpy(all.data(), dev, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < nslot / 8; ++w)
+        for (int k = 0; k < 6; ++k)
+            host[k] += all[8 * w + k];
+    CK(hipFree(dev));
+    CK(hipFree(ctr));
+    std::printf("(stamped launch: %.3f ms) ", ms);
+    const double n = (double)host[5];
+    std::printf("phases nq%d EB%d WPB%d MW%d K%d dyn%d (%d blocks/CU): shader clocks per chunk: stage+issue %.0f | step 1 %.0f | "
+                "step 2 %.0f | flush %.0f | wait next %.0f | sum %.0f (%llu chunks)\n",
+                NQ, EB, WPB, MW, K, DYNB, bpc, host[0] / n, host[1] / n, host[2] / n, host[3] / n, host[4] / n,
+                (host[0] + host[1] + host[2] + host[3] + host[4]) / n, host[5]);
+}
+
 int main(int argc, char **argv)
 {
     constexpr int NQ = TUNE_NQ, NM = NQ - 1;
@@ -137,6 +184,13 @@ int main(int argc, char **argv)
                 NQ, nelmt, g_reps);
     run("generic block/LDS (reference result)", a, [&]() { return launch_quad_generic(SF_VARIANT_BLOCK_LDS, NQ, NQ, a, 0); },
         true);
+    phases<2, 4, 2, 0, 0, 4>(a);
+    phases<2, 4, 2, 1, 64, 0>(a);
+    phases<2, 4, 2, 2, 64, 0>(a);
+    phases<1, 4, 4, 1, 64, 0>(a);
+    phases<4, 4, 1, 0, 0, 4>(a);
+    if (argc > 3) // phases only
+        return 0;
     for (int rep = 0; rep < 2; ++rep)
     {
         run("shipped wave kernel", a, [&]() { return launch_quad_wave_nq(NQ, a, 0); });
