@@ -224,6 +224,9 @@ int main(int argc, char **argv)
         m4<2, 4, 3, 4, 1, 64>(a);
         m4<2, 4, 3, 4, 2, 64>(a);
         m4<2, 4, 3, 2, 1, 64>(a);
+        m4<2, 4, 3, 4, 0, 0, 4>(a); // persistent, three waves per SIMD
+        m4<2, 4, 3, 4, 0, 0, 8>(a);
+        m4<2, 4, 3, 4, 4, 64>(a);
     }
     return 0;
 }
