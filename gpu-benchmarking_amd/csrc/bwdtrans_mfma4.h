@@ -95,7 +95,7 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // run (+3..5 %, tools/experiments/zero_data_clock.py) this rules the matrix pipe out as what bounds nq 25..31.  Off by
 // default: AUTO's results stay bit-identical to the generic kernel's.
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true,
-          bool SPLIT = false, bool STAMP = false>
+          bool SPLIT = false, bool STAMP = false, bool EFL = false>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr,
@@ -512,12 +512,27 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
                             slab[e * G::NQT + (4 * tj + hi) * NQ + 4 * TS + lo] = sum;
                     }
                 }
+                if constexpr (EFL)
+                {
+                    // EFL: the rows of this j group are final: stream them out now, so that a chunk's stores are spread
+                    // over its matrix phase instead of leaving as one burst of 13 at the end (the burst holds the wave
+                    // for 5 256 of its 17 828 clocks at nq 28, profiles/r03/mfma4_phase_stamps_nq28.log)
+                    wave_lds_fence();
+                    constexpr int ROWS = 4 * GJ;
+                    const int nrows    = NQ - 4 * j0 < ROWS ? NQ - 4 * j0 : ROWS;
+#pragma unroll
+                    for (int e2 = 0; e2 < EB; ++e2)
+                        if (e2 < evalid)
+                            flush_any<ROWS * NQ, double>(slab + e2 * G::NQT + 4 * j0 * NQ,
+                                                         out + (c * EB + e2) * (uint64_t)G::NQT + 4 * j0 * NQ, nrows * NQ, lane);
+                }
             }
         }
         wave_lds_fence();
         stamp(2);
         // 16 B per lane, every wave-wide store on whole 128-byte lines (word-grid store when nq^2 is odd and EB = 1)
-        chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
+        if constexpr (!EFL)
+            chunk_flush<GW, true, true>(slab, out + c * (uint64_t)GW::OUT_DBL, evalid * G::NQT, lane);
         wave_lds_fence(); // the slab is rewritten by the next chunk's staging
         stamp(3);
         ++nch;

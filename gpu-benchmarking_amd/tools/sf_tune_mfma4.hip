@@ -114,10 +114,10 @@ static void m4(const QuadArgs &a)
 
 // shader-clock time per phase of the chunk loop (quad_mfma4_kernel with STAMP): persistent grid fed by the batch counter,
 // or one chunk per wave
-template <int EB, int WPB, int MW, int K, int XG, int DYNB> static void phases(const QuadArgs &a)
+template <int EB, int WPB, int MW, int K, int XG, int DYNB, bool EFL = false> static void phases(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
-    auto kern        = quad_mfma4_kernel<NQ, EB, WPB, MW, 4, K, XG, true, DYNB, true, false, true>;
+    auto kern        = quad_mfma4_kernel<NQ, EB, WPB, MW, 4, K, XG, true, DYNB, true, false, true, EFL>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, true>();
     if (lds > 48 * 1024)
         CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -134,6 +134,7 @@ template <int EB, int WPB, int MW, int K, int XG, int DYNB> static void phases(c
     CK(hipMalloc((void **)&dev, nslot * sizeof(unsigned long long)));
     CK(hipMalloc((void **)&ctr, 64));
     float ms = 0;
+    CK(hipMemset(a.out, 0xff, sizeof(double) * g_nout)); // NaN pattern: unwritten outputs show up in the check
     for (int rep = 0; rep < 3; ++rep) // the last repetition is reported
     {
         CK(hipMemset(dev, 0, nslot * sizeof(unsigned long long)));
@@ -151,11 +152,17 @@ template <int EB, int WPB, int MW, int K, int XG, int DYNB> static void phases(c
             host[k] += all[8 * w + k];
     CK(hipFree(dev));
     CK(hipFree(ctr));
-    std::printf("(stamped launch: %.3f ms) ", ms);
+    double *dres, hres = 0;
+    CK(hipMalloc((void **)&dres, sizeof(double)));
+    CK(hipMemset(dres, 0, sizeof(double)));
+    maxdiff_kernel<<<1024, 256>>>(a.out, g_ref, g_nout, dres);
+    CK(hipMemcpy(&hres, dres, sizeof(double), hipMemcpyDeviceToHost));
+    CK(hipFree(dres));
+    std::printf("(stamped launch: %.3f ms, max|d| %.2e) ", ms, hres);
     const double n = (double)host[5];
-    std::printf("phases nq%d EB%d WPB%d MW%d K%d dyn%d (%d blocks/CU): shader clocks per chunk: stage+issue %.0f | step 1 %.0f | "
+    std::printf("phases%s nq%d EB%d WPB%d MW%d K%d dyn%d (%d blocks/CU): shader clocks per chunk: stage+issue %.0f | step 1 %.0f | "
                 "step 2 %.0f | flush %.0f | wait next %.0f | sum %.0f (%llu chunks)\n",
-                NQ, EB, WPB, MW, K, DYNB, bpc, host[0] / n, host[1] / n, host[2] / n, host[3] / n, host[4] / n,
+                EFL ? " [stores per j group]" : "", NQ, EB, WPB, MW, K, DYNB, bpc, host[0] / n, host[1] / n, host[2] / n, host[3] / n, host[4] / n,
                 (host[0] + host[1] + host[2] + host[3] + host[4]) / n, host[5]);
 }
 
@@ -189,6 +196,10 @@ int main(int argc, char **argv)
     phases<2, 4, 2, 2, 64, 0>(a);
     phases<1, 4, 4, 1, 64, 0>(a);
     phases<4, 4, 1, 0, 0, 4>(a);
+    phases<2, 4, 2, 0, 0, 4, true>(a);
+    phases<2, 4, 2, 1, 64, 0, true>(a);
+    phases<2, 4, 2, 2, 64, 0, true>(a);
+    phases<1, 4, 4, 1, 64, 0, true>(a);
     if (argc > 3) // phases only
         return 0;
     for (int rep = 0; rep < 2; ++rep)
