@@ -95,7 +95,7 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // run (+3..5 %, tools/experiments/zero_data_clock.py) this rules the matrix pipe out as what bounds nq 25..31.  Off by
 // default: AUTO's results stay bit-identical to the generic kernel's.
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true,
-          bool SPLIT = false, bool STAMP = false, bool EFL = false>
+          bool SPLIT = false, bool STAMP = false, bool EFL = false, int XR = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr,
@@ -140,16 +140,29 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const ChunkIter it    = chunk_iter<KMAP, WPB, XG>(nchunk, wib);
     uint64_t c = kNone, cn = kNone; // this chunk, the next one (its loads are requested while this one is computed)
     // batch counter: issue (lane 0) now, look at the value a batch later
+    // XR > 0: one ticket counter per XCD (the eight counters share the launch's 64-byte slot).  Ticket k of XCD x is batch
+    // ((k / XR) * 8 + x) * XR + k % XR: every XCD works through runs of XR neighbouring batches, and the runs of the eight
+    // XCDs interleave inside a window of 8 XR batches -- what logical_block() does for grids that cover the array
+    // (neighbours in memory share an L2, the DRAM front stays bounded).  An XCD only ever takes its own runs.
+    int xcc = 0;
+    if constexpr (XR > 0)
+    {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7;
+    }
     auto grab_issue = [&]() -> unsigned long long {
         unsigned long long v = 0;
         if (lane == 0)
-            v = __hip_atomic_fetch_add(next_batch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_fetch_add(next_batch + xcc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
     auto grab_finish = [&](unsigned long long v) -> uint64_t { // first chunk of that batch, or kNone
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        const uint64_t first = (((uint64_t)hi32 << 32) | lo32) * (uint64_t)(DYNB > 0 ? DYNB : 1);
+        uint64_t batch      = ((uint64_t)hi32 << 32) | lo32;
+        if constexpr (XR > 0)
+            batch = ((batch / XR) * 8 + (uint64_t)xcc) * XR + batch % XR;
+        const uint64_t first = batch * (uint64_t)(DYNB > 0 ? DYNB : 1);
         return first < nchunk ? first : kNone;
     };
     unsigned long long pending = 0;

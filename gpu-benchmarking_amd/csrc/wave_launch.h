@@ -13,9 +13,10 @@ namespace sf
 
 constexpr int kMaxDev = 64;
 
+// zeroes the eight ticket counters of a launch's 64-byte slot (one device-wide counter, or one per XCD)
 static __global__ void counter_reset_kernel(unsigned long long *ctr)
 {
-    __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctr + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Persistent grid: as many workgroups as the device keeps resident (occupancy query, cached per
@@ -121,11 +122,12 @@ inline int launch_quad_mfma(const QuadArgsT<T> &a, hipStream_t s, int grid_overr
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB, bool PEEL = true, bool SPLIT = false>
+template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG, bool SHB, int DYNB, bool PEEL = true, bool SPLIT = false,
+          int XR = 0>
 inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 {
     static OccCache cache = {};
-    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB, PEEL, SPLIT>;
+    auto kern            = quad_mfma4_kernel<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, DYNB, PEEL, SPLIT, false, false, XR>;
     constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, SHB>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     static_assert(DYNB == 0 || KMAP == 0, "the batch counter feeds a persistent grid");
@@ -144,10 +146,10 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
         // same kernel with a fixed share per wave
         unsigned long long *ctr = nullptr;
         if (counter_acquire(s, &ctr) != SF_OK)
-            return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0, PEEL, SPLIT>(a, s);
+            return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, SHB, 0, PEEL, SPLIT, 0>(a, s);
         // zeroed by a one-thread kernel, not a memset: under stream capture a memset node on a pointer INSIDE an
         // allocation did not zero the counter on ROCm 7.2 (the replayed grid then saw a stale ticket and exited)
-        counter_reset_kernel<<<1, 1, 0, s>>>(ctr);
+        counter_reset_kernel<<<1, 8, 0, s>>>(ctr);
         kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr, nullptr);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? SF_OK : (int)e;
@@ -162,17 +164,17 @@ inline int launch_quad_mfma4_impl(const QuadArgs &a, hipStream_t s)
 
 // SHBONLY: the configuration only fits the LDS with one basis copy (b0 == b1)
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHBONLY = false, int DYNB = 0,
-          bool PEEL = true, bool SPLIT = false>
+          bool PEEL = true, bool SPLIT = false, int XR = 0>
 inline int launch_quad_mfma4(const QuadArgs &a, hipStream_t s)
 {
     if (a.nelmt == 0)
         return SF_OK;
     if (a.b0 == a.b1)
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true, DYNB, PEEL, SPLIT>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, true, DYNB, PEEL, SPLIT, XR>(a, s);
     if constexpr (SHBONLY)
         return SF_ENOTBUILT;
     else
-        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB, PEEL, SPLIT>(a, s);
+        return launch_quad_mfma4_impl<NQ, EB, WPB, MINW, GJ, KMAP, XG, false, DYNB, PEEL, SPLIT, XR>(a, s);
 }
 
 template <int NQ, int EC, int WPB, int MINW, int KMAP, int XG = 0, typename T = double>

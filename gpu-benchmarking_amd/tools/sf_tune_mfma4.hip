@@ -92,7 +92,7 @@ template <class F> static void run(const char *label, const QuadArgs &a, F launc
     std::fflush(stdout);
 }
 
-template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEEL = true, bool SPLIT = false>
+template <int EB, int WPB, int MW, int GJ, int K, int XG, int DYNB = 0, bool PEEL = true, bool SPLIT = false, int XR = 0>
 static void m4(const QuadArgs &a)
 {
     constexpr int NQ = TUNE_NQ;
@@ -106,9 +106,9 @@ static void m4(const QuadArgs &a)
     else if constexpr (mfma4_lds_bytes<NQ, EB, WPB>() <= 160 * 1024)
     {
         char label[96];
-        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d dyn%d%s lds %zu", NQ, EB, WPB, MW, GJ, K,
-                      XG, DYNB, PEEL ? (SPLIT ? " split" : "") : " nopeel", mfma4_lds_bytes<NQ, EB, WPB>());
-        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB, PEEL, SPLIT>(a, 0); });
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d GJ%d K%d xg%d dyn%d%s xr%d lds %zu", NQ, EB, WPB, MW, GJ, K,
+                      XG, DYNB, PEEL ? (SPLIT ? " split" : "") : " nopeel", XR, mfma4_lds_bytes<NQ, EB, WPB>());
+        run(label, a, [&]() { return launch_quad_mfma4<NQ, EB, WPB, MW, GJ, K, XG, false, DYNB, PEEL, SPLIT, XR>(a, 0); });
     }
 }
 
@@ -216,6 +216,13 @@ int main(int argc, char **argv)
         m4<2, 4, 2, 4, 2, 64, 0, true, true>(a);
         m4<2, 4, 2, 4, 1, 64, 0, false>(a);
         m4<2, 4, 2, 4, 0, 0, 8>(a);
+        // batch tickets per XCD: runs of 4 / 16 / 64 neighbouring batches on one XCD
+        m4<2, 4, 2, 4, 0, 0, 4, true, false, 4>(a);
+        m4<2, 4, 2, 4, 0, 0, 4, true, false, 16>(a);
+        m4<2, 4, 2, 4, 0, 0, 4, true, false, 64>(a);
+        m4<2, 4, 2, 4, 0, 0, 2, true, false, 32>(a);
+        m4<2, 4, 2, 4, 0, 0, 1, true, false, 64>(a);
+        m4<4, 4, 1, 4, 0, 0, 4, true, false, 16>(a);
         m4<2, 8, 2, 4, 0, 0, 8>(a);
         m4<4, 4, 1, 4, 0, 0>(a);
         m4<4, 4, 1, 4, 0, 0, 4>(a);
