@@ -4,6 +4,7 @@
 // GDOF/s (min and mean), algorithmic GB/s (8*(nm^d+nq^d) B/element) and sqrt(sum out^2) as a sanity value.
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
+#include "experiments/hex_mfma2.h"
 #include "tune_guard.h"
 
 #include <algorithm>
@@ -137,6 +138,21 @@ template <int NQ, int EC, int WPB, int MW, int KM, int XG = 0> void hex_mfma_cas
         a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma<NQ, EC, WPB, MW, KM, XG>(a, 0); });
 }
 
+template <int NQ, int MW, int XG> void hex_mfma2_case(const HexArgs &a)
+{
+    if constexpr (NQ >= 14 && NQ <= 16)
+    {
+        char label[96];
+        std::snprintf(label, sizeof label, "hex nq%d MFMA two waves per element MW%d xg%d", NQ, MW, XG);
+        const double nm = NQ - 1;
+        if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
+                        sizeof(double) * (NQ - 1) * NQ))
+            return;
+        run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
+            a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma2<NQ, MW, XG>(a, 0); });
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int nq       = TUNE_NQ;
@@ -177,6 +193,13 @@ int main(int argc, char **argv)
 #define X(NQ, EC, WPB, MW, KM) hex_mfma_case<NQ, EC, WPB, MW, KM>(a);
 #define XX(NQ, EC, WPB, MW, KM, XG) hex_mfma_case<NQ, EC, WPB, MW, KM, XG>(a);
     TUNE_CASES
+    for (int rep = 0; rep < 2; ++rep)
+    {
+        hex_mfma2_case<TUNE_NQ, 1, 64>(a);
+        hex_mfma2_case<TUNE_NQ, 2, 64>(a);
+        hex_mfma2_case<TUNE_NQ, 3, 64>(a);
+        hex_mfma2_case<TUNE_NQ, 2, 0>(a);
+    }
 #else
     QuadArgs a{b0, b1, in, nullptr, out, nelmt};
 #define Q(NQ, EC, WPB, BM, MW, KM, OUT) quad_case<NQ, EC, WPB, BM, MW, KM, OUT>(a);
