@@ -95,7 +95,7 @@ template <int NQ, int EB, int WPB, bool SHB = false> constexpr size_t mfma4_lds_
 // run (+3..5 %, tools/experiments/zero_data_clock.py) this rules the matrix pipe out as what bounds nq 25..31.  Off by
 // default: AUTO's results stay bit-identical to the generic kernel's.
 template <int NQ, int EB, int WPB, int MINW, int GJ, int KMAP, int XG = 0, bool SHB = false, int DYNB = 0, bool PEEL = true,
-          bool SPLIT = false, bool STAMP = false, bool EFL = false, int XR = 0>
+          bool SPLIT = false, bool STAMP = false, bool EFL = false, int XR = 0, int ST = 0>
 __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ in,
     double *__restrict__ out, uint64_t nelmt, unsigned long long *next_batch = nullptr,
@@ -144,16 +144,23 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
     // ((k / XR) * 8 + x) * XR + k % XR: every XCD works through runs of XR neighbouring batches, and the runs of the eight
     // XCDs interleave inside a window of 8 XR batches -- what logical_block() does for grids that cover the array
     // (neighbours in memory share an L2, the DRAM front stays bounded).  An XCD only ever takes its own runs.
+    // ST > 0: ST ticket counters, 128 bytes apart (a line of their own each: one line takes ~80 M atomics/s, which is
+    // what forces batches on a single counter); wave w draws from counter w % ST, whose ticket k is batch k * ST + w % ST.
+    // The counters advance at the same average rate, so the batches in flight stay neighbours in memory even at one
+    // chunk per batch.
     int xcc = 0;
     if constexpr (XR > 0)
     {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7;
     }
+    static_assert(XR == 0 || ST == 0, "one ticket scheme at a time");
+    if constexpr (ST > 0)
+        xcc = (int)((blockIdx.x * WPB + wib) % ST);
     auto grab_issue = [&]() -> unsigned long long {
         unsigned long long v = 0;
         if (lane == 0)
-            v = __hip_atomic_fetch_add(next_batch + xcc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_fetch_add(next_batch + (ST > 0 ? 16 * xcc : xcc), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
     auto grab_finish = [&](unsigned long long v) -> uint64_t { // first chunk of that batch, or kNone
@@ -162,6 +169,8 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void quad_mfma4_kernel(
         uint64_t batch      = ((uint64_t)hi32 << 32) | lo32;
         if constexpr (XR > 0)
             batch = ((batch / XR) * 8 + (uint64_t)xcc) * XR + batch % XR;
+        if constexpr (ST > 0)
+            batch = batch * ST + (uint64_t)xcc;
         const uint64_t first = batch * (uint64_t)(DYNB > 0 ? DYNB : 1);
         return first < nchunk ? first : kNone;
     };

@@ -73,8 +73,8 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
-        // anisotropic extents, or buffers that are only 8-byte aligned: the run-time-extent wave kernel up to nq = 16
-        // per direction (bwdtrans_rt.h), the barrier-per-sweep block kernel beyond
+        // anisotropic extents, or buffers that are only 8-byte aligned: the compile-time triples of bwdtrans_rt.hip, then
+        // the run-time-extent wave kernel (bwdtrans_rt.h), then the barrier-per-sweep block kernel
         int rc = (!iso && vec_ok) ? launch_hex_wave3(nq0, nq1, nq2, a, s) : SF_ENOTBUILT; // compile-time triples
         // the run-time-extent kernel is ahead of the block kernel up to nq = 8 per direction (0.39-0.52 of the roofline
         // against 0.28-0.34; above that its unrolled-to-the-bound loops lose: profiles/r03/anisotropic_shapes.log)

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #ifndef TUNE_NQ
@@ -112,6 +113,37 @@ static void m4(const QuadArgs &a)
     }
 }
 
+// ST ticket counters in lines of their own (quad_mfma4_kernel's ST): small batches without the one-line atomic limit
+template <int EB, int WPB, int MW, int DYNB, int ST, int GW = 0> static void m4s(const QuadArgs &a)
+{
+    constexpr int NQ = TUNE_NQ;
+    constexpr size_t lds = mfma4_lds_bytes<NQ, EB, WPB, true>();
+    if constexpr (lds <= 160 * 1024)
+    {
+        auto kern = quad_mfma4_kernel<NQ, EB, WPB, MW, 4, 0, 0, true, DYNB, true, false, false, false, 0, ST>;
+        if (lds > 48 * 1024)
+            CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int bpc = 0, cus = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, kWave * WPB, lds));
+        CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+        const uint64_t nchunk = (a.nelmt + EB - 1) / EB, need = (nchunk + WPB - 1) / WPB;
+        uint64_t grid         = (uint64_t)(GW > 0 ? GW : bpc) * cus;
+        if (grid > need)
+            grid = need;
+        static unsigned long long *ctr = nullptr;
+        if (!ctr)
+            CK(hipMalloc((void **)&ctr, 128 * 64));
+        char label[96];
+        std::snprintf(label, sizeof label, "quad nq%d MFMA4 EB%d WPB%d MW%d K0 dyn%d striped%d (%d wg/CU) lds %zu", NQ, EB, WPB, MW, DYNB,
+                      ST, GW > 0 ? GW : bpc, lds);
+        run(label, a, [&]() {
+            (void)hipMemsetAsync(ctr, 0, 128 * 64, 0);
+            kern<<<(unsigned)grid, kWave * WPB, lds>>>(a.b0, a.b1, a.in, a.out, a.nelmt, ctr, nullptr);
+            return (int)hipGetLastError();
+        });
+    }
+}
+
 // shader-clock time per phase of the chunk loop (quad_mfma4_kernel with STAMP): persistent grid fed by the batch counter,
 // or one chunk per wave
 template <int EB, int WPB, int MW, int K, int XG, int DYNB, bool EFL = false> static void phases(const QuadArgs &a)
@@ -191,6 +223,28 @@ int main(int argc, char **argv)
                 NQ, nelmt, g_reps);
     run("generic block/LDS (reference result)", a, [&]() { return launch_quad_generic(SF_VARIANT_BLOCK_LDS, NQ, NQ, a, 0); },
         true);
+    if (argc > 3 && std::string(argv[3]) == "striped")
+    {
+        for (int rep = 0; rep < 2; ++rep)
+        {
+            m4<2, 4, 2, 4, 0, 0, 4>(a);
+            m4<2, 4, 2, 4, 0, 0, 8>(a);
+            m4s<2, 4, 2, 4, 1>(a); // the single counter through this launcher
+            m4s<2, 4, 2, 4, 16>(a);
+            m4s<2, 4, 2, 2, 16>(a);
+            m4s<2, 4, 2, 1, 16>(a);
+            m4s<2, 4, 2, 1, 64>(a);
+            m4s<2, 4, 2, 2, 64>(a);
+            m4s<2, 4, 2, 1, 8>(a);
+            m4s<4, 4, 1, 1, 16>(a);
+            m4s<4, 4, 1, 2, 16>(a);
+            m4s<4, 4, 1, 1, 64>(a);
+            m4s<1, 4, 4, 1, 64>(a);
+            m4s<1, 4, 4, 2, 64>(a);
+            m4s<1, 4, 3, 1, 64>(a);
+        }
+        return 0;
+    }
     phases<2, 4, 2, 0, 0, 4>(a);
     phases<2, 4, 2, 1, 64, 0>(a);
     phases<2, 4, 2, 2, 64, 0>(a);
