@@ -30,7 +30,9 @@ enum Mode
     M4B = 1,  // v_mfma_f64_4x4x4_4b_f64: 512 flop
     VFMA = 2, // v_fma_f64: 128 flop
     MIX16 = 3, // one 16x16x4 MFMA + 16 FMAs per group (equal flops on both pipes)
-    MIX4 = 4   // one 4x4x4_4b MFMA + 4 FMAs per group
+    MIX4 = 4,  // one 4x4x4_4b MFMA + 4 FMAs per group
+    M16F = 5,  // v_mfma_f32_16x16x4_f32: 2048 flop
+    PKF = 6    // v_pk_fma_f32: 256 flop
 };
 
 template <int MODE> __global__ __launch_bounds__(64) void rate_kernel(int iters, double *sink, long long *cycles)
@@ -39,9 +41,16 @@ template <int MODE> __global__ __launch_bounds__(64) void rate_kernel(int iters,
     double4_t c16[4] = {};
     double c4[8]     = {};
     double v[16];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f4 f16[4] = {};
+    f2 pk[16], pka = {(float)a, (float)b}, pkb = {(float)b, (float)a};
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        v[k] = k;
+    {
+        v[k]  = k;
+        pk[k] = f2{(float)k, (float)k};
+    }
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it)
     {
@@ -73,6 +82,18 @@ template <int MODE> __global__ __launch_bounds__(64) void rate_kernel(int iters,
                 }
             }
         }
+        if constexpr (MODE == M16F)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                f16[k] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)a, (float)b, f16[k], 0, 0, 0);
+        }
+        if constexpr (MODE == PKF)
+        {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[j]) : "v"(pka), "v"(pkb));
+        }
         if constexpr (MODE == VFMA)
         {
 #pragma unroll
@@ -90,7 +111,10 @@ template <int MODE> __global__ __launch_bounds__(64) void rate_kernel(int iters,
         s += c4[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        s += v[k];
+        s += v[k] + pk[k].x + pk[k].y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        s += f16[k][0] + f16[k][1] + f16[k][2] + f16[k][3];
     sink[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0)
         cycles[blockIdx.x] = t1 - t0;
@@ -123,6 +147,10 @@ template <int MODE> static void rate(const char *name, int cus, int wps, int ite
         mfma_flop = 8 * 512.0, n_mfma = 8;
     if (MODE == VFMA)
         valu_flop = 16 * 128.0, n_valu = 16;
+    if (MODE == M16F)
+        mfma_flop = 4 * 2048.0, n_mfma = 4;
+    if (MODE == PKF)
+        valu_flop = 16 * 256.0, n_valu = 16;
     if (MODE == MIX16)
         valu_flop = 64 * 128.0, n_valu = 64;
     if (MODE == MIX4)
@@ -165,6 +193,8 @@ int main(int argc, char **argv)
     {
         rate<M16>("mfma_f64_16x16x4", cus, wps, iters, sink, cyc);
         rate<M4B>("mfma_f64_4x4x4_4b", cus, wps, iters, sink, cyc);
+        rate<M16F>("mfma_f32_16x16x4", cus, wps, iters, sink, cyc);
+        rate<PKF>("pk_fma_f32", cus, wps, iters, sink, cyc);
         rate<VFMA>("v_fma_f64", cus, wps, iters, sink, cyc);
         rate<MIX16>("16x16x4 + 16 fma", cus, wps, iters / 4, sink, cyc);
         rate<MIX4>("4x4x4_4b + 4 fma", cus, wps, iters / 2, sink, cyc);
