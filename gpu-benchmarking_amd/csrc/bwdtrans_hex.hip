@@ -161,6 +161,41 @@ int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
     }
 }
 
+// 4x4x4_4b matrix-core kernel (bwdtrans_hmfma4.h, hex_mfma4_kernel): orders 12..16, one element per wave.
+// profiles/r03/tune_hex1[2-6]_mfma_4x4x4.log (131 072 elements, mean GDOF/s = fraction of the HBM roofline; in brackets
+// the 16x16x4 kernel in the same run): 12: 327 = 0.75 (300-315)   13: 316 (323-329)   14: 285 (283-287)   15: 278 (290-292)
+// 16: 319 = 0.72 with the accumulators stored directly and unpadded W2 rows (five workgroups per CU), 310 through the LDS
+// output image (290-307).  AUTO runs it at nq 12 and 16 (hex_auto_kernel()).
+template <int NQ> static int go_mfma4(const HexArgs &a, hipStream_t s)
+{
+    // SF_HEX_MFMA4_CFG is a development knob, read at every call (1: output through an LDS image, 3: accumulators stored
+    // directly -- whole 128-byte lines only where nq is a multiple of 4 and `out` is 128-byte aligned)
+    const char *env = getenv("SF_HEX_MFMA4_CFG");
+    const int cfg   = env ? atoi(env) : (NQ == 16 ? 3 : 1);
+    if (cfg == 3)
+        return launch_hex_mfma4<NQ, 1, 2, 1, 64, true>(a, s);
+    return launch_hex_mfma4<NQ, 1, (NQ == 12 ? 1 : 2), 1, 64>(a, s);
+}
+
+int launch_hex_mfma4_nq(unsigned nq, const HexArgs &a, hipStream_t s)
+{
+    switch (nq)
+    {
+    case 12: return go_mfma4<12>(a, s);
+    case 13: return go_mfma4<13>(a, s);
+    case 14: return go_mfma4<14>(a, s);
+    case 15: return go_mfma4<15>(a, s);
+    case 16: return go_mfma4<16>(a, s);
+    default: return SF_ENOTBUILT;
+    }
+}
+
+// the measured best matrix-core kernel above the wave kernel's table
+int hex_auto_kernel(unsigned nq)
+{
+    return (nq == 12 || nq == 16) ? SF_VARIANT_MFMA4 : SF_VARIANT_MFMA;
+}
+
 // fp32 (T = float): same kernels with float4 lanes.  Chunks hold twice the fp64 element count (same
 // bytes), always the LDS-staged flat output (the DPP pair store is the fp64 path).
 // nq = 2, T = float: the stream form of hex_nq2_stream_kernel with float4 lanes -- one 16-byte vector per thread holds the

@@ -68,8 +68,8 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
         if (iso && vec_ok)
         {
             int rc = launch_hex_wave_nq(nq0, a, s);
-            if (rc == SF_ENOTBUILT) // above the wave kernel's table: matrix-core kernel (nq 11..16)
-                rc = launch_hex_mfma_nq(nq0, a, s);
+            if (rc == SF_ENOTBUILT) // above the wave kernel's table: the measured best matrix-core kernel (nq 12..16)
+                rc = hex_auto_kernel(nq0) == SF_VARIANT_MFMA4 ? launch_hex_mfma4_nq(nq0, a, s) : launch_hex_mfma_nq(nq0, a, s);
             if (rc != SF_ENOTBUILT)
                 return rc;
         }
@@ -96,6 +96,12 @@ int sf_bwdtrans_hex_f64_variant(int variant, unsigned nq0, unsigned nq1, unsigne
         if (!vec_ok)
             return SF_EALIGN;
         return launch_hex_mfma_nq(nq0, a, s);
+    case SF_VARIANT_MFMA4:
+        if (!iso)
+            return SF_ENOTBUILT;
+        if (!vec_ok)
+            return SF_EALIGN;
+        return launch_hex_mfma4_nq(nq0, a, s);
     case SF_VARIANT_GENERIC:
         return launch_hex_generic(SF_VARIANT_GENERIC, nq0, nq1, nq2, a, s);
     case SF_VARIANT_THREAD:

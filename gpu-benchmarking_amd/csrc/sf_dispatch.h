@@ -11,6 +11,8 @@ namespace sf
 {
 int launch_hex_wave_nq(unsigned nq, const HexArgs &a, hipStream_t s);
 int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s);
+int launch_hex_mfma4_nq(unsigned nq, const HexArgs &a, hipStream_t s);
+int hex_auto_kernel(unsigned nq); // SF_VARIANT_MFMA / SF_VARIANT_MFMA4 above the wave kernel's table
 int launch_quad_wave_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 int launch_quad_mfma_nq(unsigned nq, const QuadArgs &a, hipStream_t s);
 int launch_quad_mfma4_nq(unsigned nq, const QuadArgs &a, hipStream_t s);

@@ -3,6 +3,7 @@
 
 #include "bwdtrans_mfma.h"
 #include "bwdtrans_mfma4.h"
+#include "bwdtrans_hmfma4.h"
 #include "bwdtrans_wave.h"
 #include "sf_dispatch.h" // counter_acquire (batch counter of the persistent 2D kernels)
 
@@ -197,6 +198,29 @@ inline int launch_hex_mfma(const HexArgsT<T> &a, hipStream_t s, int grid_overrid
     if (grid > 0x7fffffffull)
         return SF_EINVAL;
     kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SF_OK : (int)e;
+}
+
+template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool DIRECT = false>
+inline int launch_hex_mfma4(const HexArgs &a, hipStream_t s, int grid_override = 0)
+{
+    static OccCache cache = {};
+    auto kern            = hex_mfma4_kernel<NQ, WPB, MINW, KMAP, XG, false, DIRECT>;
+    constexpr size_t lds = hex_mfma4_lds_bytes<NQ, WPB, DIRECT>();
+    static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
+    if (a.nelmt == 0)
+        return SF_OK;
+    const uint64_t per  = (uint64_t)WPB * (KMAP > 0 ? KMAP : (KMAP < 0 ? -KMAP : 1));
+    const uint64_t need = (a.nelmt + per - 1) / per;
+    uint64_t grid       = (uint64_t)resident_blocks(kern, kWave * WPB, lds, cache);
+    if (grid_override > 0)
+        grid = (uint64_t)grid_override;
+    if (grid > need || KMAP != 0)
+        grid = need;
+    if (grid > 0x7fffffffull)
+        return SF_EINVAL;
+    kern<<<(unsigned)grid, kWave * WPB, lds, s>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt, nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SF_OK : (int)e;
 }

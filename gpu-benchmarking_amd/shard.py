@@ -36,7 +36,7 @@ def aggregate_gdofs(total_elements, nm_tot, steps, max_elapsed_s):
 
 KERNEL_SOURCES = ("bwdtrans_wave.h", "wave_table.h", "bwdtrans_hex.hip", "bwdtrans_quad.hip",
                   "bwdtrans_mfma.h", "bwdtrans_mfma4.h", "sf_common.h", "wave_launch.h",
-                  "bwdtrans_wave3.h", "bwdtrans_rt.h", "bwdtrans_rt.hip")
+                  "bwdtrans_wave3.h", "bwdtrans_rt.h", "bwdtrans_rt.hip", "bwdtrans_hmfma4.h")
 
 
 def kernel_source_hash(root):

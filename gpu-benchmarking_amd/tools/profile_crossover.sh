@@ -50,4 +50,8 @@ for shape in "8 8 4" "4 8 6" "10 6 8"; do
   run hex_$1x$2x$3_auto "$here/bin/benchmark05" $1 $2 $3 --nelmt $N --no-baselines --data random --variant auto || exit 1
   run hex_$1x$2x$3_wave-rt "$here/bin/benchmark05" $1 $2 $3 --nelmt $N --no-baselines --data random --variant wave-rt || exit 1
 done
+# round 3: the 3D 4x4x4_4b matrix-core kernel (bwdtrans_hmfma4.h; AUTO at nq 12 and 16)
+for nq in 12 14 16; do
+  run hex_nq${nq}_mfma4 "$here/bin/benchmark05" $nq $nq $nq --nelmt $M --no-baselines --data random --variant mfma4 || exit 1
+done
 echo all-done

@@ -5,6 +5,7 @@
 #include "../csrc/sf_dispatch.h"
 #include "../csrc/wave_launch.h"
 #include "experiments/hex_mfma2.h"
+#include "experiments/hex_mfma4_pair.h"
 #include "tune_guard.h"
 
 #include <algorithm>
@@ -153,6 +154,79 @@ template <int NQ, int MW, int XG> void hex_mfma2_case(const HexArgs &a)
     }
 }
 
+template <int NQ, int WPB, int MW, int K, int XG, bool DIRECT = false> void hex_mfma4_case(const HexArgs &a)
+{
+    if constexpr (NQ >= 9 && NQ <= 16 && hex_mfma4_lds_bytes<NQ, WPB>() <= 160 * 1024)
+    {
+        char label[96];
+        std::snprintf(label, sizeof label, "hex nq%d MFMA 4x4x4 WPB%d MW%d K%d xg%d%s", NQ, WPB, MW, K, XG, DIRECT ? " direct" : "");
+        const double nm = NQ - 1;
+        if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
+                        sizeof(double) * (NQ - 1) * NQ))
+            return;
+        run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
+            a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma4<NQ, WPB, MW, K, XG, DIRECT>(a, 0); });
+    }
+}
+
+template <int NQ, int MW, int XG> void hex_mfma4_pair_case(const HexArgs &a)
+{
+    if constexpr (NQ >= 9 && NQ <= 16)
+    {
+        char label[96];
+        std::snprintf(label, sizeof label, "hex nq%d MFMA 4x4x4 two waves per element MW%d xg%d", NQ, MW, XG);
+        const double nm = NQ - 1;
+        if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
+                        sizeof(double) * (NQ - 1) * NQ))
+            return;
+        run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
+            a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma4_pair<NQ, MW, XG>(a, 0); });
+    }
+}
+
+// shader-clock time per phase of hex_mfma4_kernel's element loop (STAMP)
+template <int NQ, int WPB, int MW, int K, int XG, bool DIRECT = false> void hex_mfma4_phases(const HexArgs &a)
+{
+    if constexpr (NQ >= 9 && NQ <= 16 && hex_mfma4_lds_bytes<NQ, WPB>() <= 160 * 1024)
+    {
+        auto kern            = hex_mfma4_kernel<NQ, WPB, MW, K, XG, true, DIRECT>;
+        constexpr size_t lds = hex_mfma4_lds_bytes<NQ, WPB, DIRECT>();
+        if (lds > 48 * 1024)
+            CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int bpc = 0, cus = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, kWave * WPB, lds));
+        CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+        const uint64_t per = (uint64_t)WPB * (K > 0 ? K : 1), need = (a.nelmt + per - 1) / per;
+        uint64_t grid      = (uint64_t)bpc * cus;
+        if (K != 0 || grid > need)
+            grid = need;
+        const size_t nslot = (size_t)grid * WPB * 8;
+        unsigned long long *dev, host[8] = {};
+        CK(hipMalloc((void **)&dev, nslot * sizeof(unsigned long long)));
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep)
+        {
+            CK(hipMemset(dev, 0, nslot * sizeof(unsigned long long)));
+            CK(hipEventRecord(g_e0, 0));
+            kern<<<(unsigned)grid, kWave * WPB, lds>>>(a.b0, a.b1, a.b2, a.in, a.out, a.nelmt, dev);
+            CK(hipEventRecord(g_e1, 0));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+        }
+        std::vector<unsigned long long> all(nslot);
+        CK(hipMemcpy(all.data(), dev, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < nslot / 8; ++w)
+            for (int k = 0; k < 6; ++k)
+                host[k] += all[8 * w + k];
+        CK(hipFree(dev));
+        const double n = (double)host[5];
+        std::printf("phases%s hex nq%d 4x4x4 WPB%d MW%d K%d (%d wg/CU, stamped launch %.3f ms): clocks per element: stage+issue %.0f | "
+                    "sweeps 1+2 %.0f | sweep 3 %.0f | image+flush %.0f | wait next %.0f | sum %.0f (%llu elements)\n",
+                    DIRECT ? " [direct stores]" : "", NQ, WPB, MW, K, bpc, ms, host[0] / n, host[1] / n, host[2] / n, host[3] / n, host[4] / n,
+                    (host[0] + host[1] + host[2] + host[3] + host[4]) / n, host[5]);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int nq       = TUNE_NQ;
@@ -193,8 +267,33 @@ int main(int argc, char **argv)
 #define X(NQ, EC, WPB, MW, KM) hex_mfma_case<NQ, EC, WPB, MW, KM>(a);
 #define XX(NQ, EC, WPB, MW, KM, XG) hex_mfma_case<NQ, EC, WPB, MW, KM, XG>(a);
     TUNE_CASES
+    hex_mfma4_phases<TUNE_NQ, 1, 1, 1, 64>(a);
+    hex_mfma4_phases<TUNE_NQ, 1, 2, 1, 64>(a);
+    hex_mfma4_phases<TUNE_NQ, 1, 1, 0, 0>(a);
+    hex_mfma4_phases<TUNE_NQ, 1, 1, 4, 64>(a);
+    hex_mfma4_phases<TUNE_NQ, 1, 1, 1, 64, true>(a);
+    hex_mfma4_phases<TUNE_NQ, 1, 2, 1, 64, true>(a);
     for (int rep = 0; rep < 2; ++rep)
     {
+        hex_mfma4_pair_case<TUNE_NQ, 2, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 1, 1, 64, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 1, 64, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 3, 1, 64, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 1, 0, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 0, 0, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 2, 64, true>(a);
+        hex_mfma4_case<TUNE_NQ, 2, 2, 1, 64, true>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 1, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 1, 0, 0>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 0, 0>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 1, 2, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 1, 4, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 2, 1, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 2, 2, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 4, 1, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 4, 2, 1, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 4, 2, 0, 0>(a);
         hex_mfma2_case<TUNE_NQ, 1, 64>(a);
         hex_mfma2_case<TUNE_NQ, 2, 64>(a);
         hex_mfma2_case<TUNE_NQ, 3, 64>(a);

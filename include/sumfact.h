@@ -52,7 +52,7 @@ enum
 };
 
 /* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest measured: 3D isotropic nq 2..11
- * WAVE, 12..16 MFMA; 2D isotropic nq 2..20 WAVE, 21..31 MFMA4, 32 MFMA; 3D anisotropic extents: WAVE where the shape
+ * WAVE, 12 and 16 MFMA4, 13..15 MFMA; 2D isotropic nq 2..20 WAVE, 21..31 MFMA4, 32 MFMA; 3D anisotropic extents: WAVE where the shape
  * is one of the compile-time triples of csrc/bwdtrans_rt.hip, else WAVE_RT up to nq = 8 per direction (also taken for
  * isotropic shapes in buffers that are only 8-byte aligned); anything else (2D anisotropic, any higher order) GENERIC,
  * which runs every extent: LDS-resident while one element's images fit the
@@ -67,7 +67,7 @@ enum
     SF_VARIANT_BLOCK_GLB  = 4, /* one workgroup per element, global workspace (cf. :203-289)       */
     SF_VARIANT_GENERIC    = 5, /* runtime-nq fallback (anisotropic nq0 != nq1 != nq2)              */
     SF_VARIANT_MFMA       = 6, /* v_mfma_f64_16x16x4 chained GEMMs: 2D quad nq 11..32, 3D hex nq 4..16 */
-    SF_VARIANT_MFMA4      = 7, /* v_mfma_f64_4x4x4_4b chained products (tile granularity 4): 2D quad nq 8..32 */
+    SF_VARIANT_MFMA4      = 7, /* v_mfma_f64_4x4x4_4b chained products (tile granularity 4): 2D quad nq 8..32, 3D hex nq 12..16 */
     SF_VARIANT_WAVE_RT    = 8, /* one wavefront per chunk with RUN-TIME extents: 3D, any extents up to 16 per direction */
     SF_NUM_VARIANTS       = 9
 };

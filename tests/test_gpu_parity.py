@@ -109,6 +109,28 @@ def test_hex_mfma_parity_all_orders(sf, oracle, nq):
             assert err <= TOL, (nq, nelmt, err)
 
 
+@pytest.mark.parametrize("nq", range(12, 17))
+def test_hex_mfma4_parity_all_orders(sf, oracle, nq):
+    """3D kernel on v_mfma_f64_4x4x4_4b (csrc/bwdtrans_hmfma4.h; AUTO runs it at nq 12 and 16): every order it is built
+    for, both output paths, ragged element counts, plus more elements than the grid has waves with distinct bases per
+    direction."""
+    import os
+    try:
+        for cfg in ("1", "3"):  # output through an LDS image / accumulators stored directly
+            os.environ["SF_HEX_MFMA4_CFG"] = cfg
+            for nelmt in (1, 2, 3, 7, 64, 129, 600):
+                err = _hex_case(sf, oracle, (nq,) * 3, nelmt, "mfma4", seed=nelmt + nq)
+                assert err <= TOL, (cfg, nq, nelmt, err)
+            nelmt = 5003
+            bs = [sf.fill_random((nq - 1) * nq, 11 + d) for d in range(3)]
+            x = sf.fill_random(nelmt * (nq - 1) ** 3, 5 + nq)
+            got = sf.bwdtrans_hex((nq,) * 3, *bs, x, variant="mfma4")
+            ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *[_np(b) for b in bs], _np(x))
+            assert oracle.rel_err(_np(got), ref) <= TOL, cfg
+    finally:
+        os.environ.pop("SF_HEX_MFMA4_CFG", None)
+
+
 RT_SHAPES = [(8, 8, 4), (4, 8, 6), (10, 6, 8), (2, 2, 2), (2, 16, 3), (16, 2, 2), (3, 2, 5), (7, 7, 7), (5, 9, 13),
              (16, 16, 16), (15, 16, 14), (12, 3, 9)]
 
