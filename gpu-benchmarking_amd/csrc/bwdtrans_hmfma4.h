@@ -67,7 +67,7 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
 // for the next element / elements)
 // DIRECT: the sweep-3 accumulators of a pos group go straight to HBM (lane: 4 k rows x 16 consecutive pos = four 128-byte
 // runs per instruction) instead of through an output image in LDS: no 64 live accumulators, no image / flush phase
-template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool STAMP = false, bool DIRECT = false>
+template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool STAMP = false, bool DIRECT = false, bool NTS = true>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
     const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt, unsigned long long *stamps = nullptr)
@@ -245,7 +245,12 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
                 {
                     const int k = 4 * tk + hi, pos = 16 * cg + 4 * blk + lo;
                     if (k < NQ && pos < NQ2)
-                        __builtin_nontemporal_store(oc[tk], oe + k * NQ2 + pos);
+                    {
+                        if constexpr (NTS)
+                            __builtin_nontemporal_store(oc[tk], oe + k * NQ2 + pos);
+                        else
+                            oe[k * NQ2 + pos] = oc[tk]; // partial lines of neighbouring pos groups meet in the L2
+                    }
                 }
             }
         }
