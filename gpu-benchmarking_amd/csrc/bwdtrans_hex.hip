@@ -163,9 +163,10 @@ int launch_hex_mfma_nq(unsigned nq, const HexArgs &a, hipStream_t s)
 
 // 4x4x4_4b matrix-core kernel (bwdtrans_hmfma4.h, hex_mfma4_kernel): orders 12..16, one element per wave.
 // profiles/r03/tune_hex1[2-6]_mfma_4x4x4.log (131 072 elements, mean GDOF/s = fraction of the HBM roofline; in brackets
-// the 16x16x4 kernel in the same run): 12: 327 = 0.75 (300-315)   13: 316 (323-329)   14: 285 (283-287)   15: 278 (290-292)
-// 16: 319 = 0.72 with the accumulators stored directly and unpadded W2 rows (five workgroups per CU), 310 through the LDS
-// output image (290-307).  AUTO runs it at nq 12 and 16 (hex_auto_kernel()).
+// the 16x16x4 kernel in the same run): 12: 327 = 0.75 (300-315)   13: 316 (323-329)   14: 293 = 0.675 with the k remainder
+// peeled onto the vector pipe, 279 without (283-287)   15: 271 peeled, 274 not (290-292)   16: 319 = 0.72 with the
+// accumulators stored directly and unpadded W2 rows (five workgroups per CU), 310 through the LDS output image (290-307).
+// AUTO runs it at nq 12, 14 and 16 (hex_auto_kernel()).
 template <int NQ> static int go_mfma4(const HexArgs &a, hipStream_t s)
 {
     // SF_HEX_MFMA4_CFG is a development knob, read at every call (1: output through an LDS image, 3: accumulators stored
@@ -193,7 +194,7 @@ int launch_hex_mfma4_nq(unsigned nq, const HexArgs &a, hipStream_t s)
 // the measured best matrix-core kernel above the wave kernel's table
 int hex_auto_kernel(unsigned nq)
 {
-    return (nq == 12 || nq == 16) ? SF_VARIANT_MFMA4 : SF_VARIANT_MFMA;
+    return (nq == 12 || nq == 14 || nq == 16) ? SF_VARIANT_MFMA4 : SF_VARIANT_MFMA;
 }
 
 // fp32 (T = float): same kernels with float4 lanes.  Chunks hold twice the fp64 element count (same

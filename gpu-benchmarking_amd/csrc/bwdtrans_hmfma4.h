@@ -62,12 +62,27 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// v of lane src (any lane pattern): two 32-bit ds_bpermute
+__device__ __forceinline__ double lane_gather(double v, int src)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int l = __builtin_amdgcn_ds_bpermute(4 * src, (int)b);
+    const int h = __builtin_amdgcn_ds_bpermute(4 * src, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)h << 32) | (unsigned)l);
+}
+
 // STAMP (tools/sf_tune only; no product instantiation): shader-clock time per phase of the element loop, summed per wave
 // into stamps[8 * wave + 0..5] (staging + next loads issued / sweeps 1 + 2 / sweep 3 / output image + flush issued / wait
 // for the next element / elements)
 // DIRECT: the sweep-3 accumulators of a pos group go straight to HBM (lane: 4 k rows x 16 consecutive pos = four 128-byte
 // runs per instruction) instead of through an output image in LDS: no 64 live accumulators, no image / flush phase
-template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool STAMP = false, bool DIRECT = false, bool NTS = true>
+// PEEL: where nm leaves a remainder of one or two over a multiple of four (nm = 13, 14: nq = 14, 15) the last 4-wide k step
+// of all three contractions is all but empty; those one or two p / q / r go through the vector pipe instead (one v_fma_f64
+// per accumulator and remaining k), which removes a quarter of the matrix instructions.  nq 14 / 15 issue 8.1 / 7.1
+// padded flops per byte of traffic without it (nq 12 / 13 / 16: 5.8 / 6.3 / 6.3) and run at 0.65 of the roofline where
+// those reach 0.72-0.75.  The sums stay in ascending order of k (matrix steps first, the peeled remainder last).
+template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool STAMP = false, bool DIRECT = false, bool NTS = true,
+          bool PEEL = true>
 __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
     const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
     const double *__restrict__ in, double *__restrict__ out, uint64_t nelmt, unsigned long long *stamps = nullptr)
@@ -84,6 +99,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
     };
     using G = HexMfma4Geom<NQ, DIRECT>;
     constexpr int NM = G::NM, NQ2 = G::NQ2, TP = G::TP, TI = G::TI, CG = G::CG, S = G::S, W2S = G::W2S;
+    constexpr int RQ = (PEEL && (NM % 4 == 1 || NM % 4 == 2)) ? NM % 4 : 0; // k values contracted on the vector pipe
+    constexpr int KM = RQ ? NM / 4 : TP;                                     // 4-wide k steps on the matrix pipe
+    constexpr int RQ1 = RQ ? RQ : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_hexmfma4[];
     double *lds    = reinterpret_cast<double *>(lds_raw_hexmfma4);
@@ -100,9 +118,9 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
     chunk_load_any<G::NMT, G::NLD, double>(st, in + it.first * G::NMT, lane, G::NMT);
 
     // basis operands (zero outside nm x nq), loaded under the first element's HBM latency
-    double opB0[TP], opB1[TI][TP], opB2[TI][TP];
+    double opB0[KM], opB1[TI][KM], opB2[TI][KM];
 #pragma unroll
-    for (int kp = 0; kp < TP; ++kp)
+    for (int kp = 0; kp < KM; ++kp)
     {
         const int p = 4 * kp + hi, i = 4 * blk + lo;
         opB0[kp]    = (p < NM && i < NQ) ? b0[p * NQ + i] : 0.0; // B[k = p][col = i]
@@ -110,22 +128,45 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
 #pragma unroll
     for (int t = 0; t < TI; ++t)
 #pragma unroll
-        for (int ks = 0; ks < TP; ++ks)
+        for (int ks = 0; ks < KM; ++ks)
         {
             const int kk = 4 * ks + hi, o = 4 * t + lo; // A[row = o (j or k)][k = kk (q or r)]
             opB1[t][ks]  = (kk < NM && o < NQ) ? b1[kk * NQ + o] : 0.0;
             opB2[t][ks]  = (kk < NM && o < NQ) ? b2[kk * NQ + o] : 0.0;
         }
+    // the peeled k values 4 KM + u work on the accumulators where they are (D layout: row on hi, column on (blk, lo)):
+    // pb0[u] = B0[k][i = 4 blk + lo], pb1[t][u] = B1[k][j = 4 t + hi], pb2[t][u] = B2[k][k' = 4 t + hi]
+    double pb0[RQ1], pb1[TI][RQ1], pb2[TI][RQ1];
+#pragma unroll
+    for (int u = 0; u < RQ; ++u)
+    {
+        const int kk = 4 * KM + u, i = 4 * blk + lo;
+        pb0[u]       = i < NQ ? b0[kk * NQ + i] : 0.0;
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+        {
+            const int o = 4 * t + hi;
+            pb1[t][u]   = o < NQ ? b1[kk * NQ + o] : 0.0;
+            pb2[t][u]   = o < NQ ? b2[kk * NQ + o] : 0.0;
+        }
+    }
     // sweep-1 gather offsets inside a slice: row q = 4 tq + lo, column p = 4 kp + hi, clamped into the element
-    int aoff[TP][TP];
+    int aoff[TP][KM];
 #pragma unroll
     for (int tq = 0; tq < TP; ++tq)
 #pragma unroll
-        for (int kp = 0; kp < TP; ++kp)
+        for (int kp = 0; kp < KM; ++kp)
         {
             const int q = 4 * tq + lo, p = 4 * kp + hi;
             aoff[tq][kp] = (q < NM ? q : NM - 1) * S + (p < NM ? p : NM - 1);
         }
+    int poff[TP]; // peeled p of row q = 4 tq + hi (the accumulator's row)
+#pragma unroll
+    for (int tq = 0; tq < TP; ++tq)
+    {
+        const int q = 4 * tq + hi;
+        poff[tq]    = (q < NM ? q : NM - 1) * S + 4 * KM;
+    }
 
     uint64_t c = it.first;
     for (uint64_t n = 0; n < it.count; ++n, c += it.step)
@@ -154,38 +195,57 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
         // cover an LDS round trip: the sixteen sweep-1 operands of slice r + 1 are requested before the products of
         // slice r are issued (sweep 3: the operands of the next pos group).
         double w2[NM][TI];
-        double av[2][TP][TP];
-        auto gather = [&](double (&dst)[TP][TP], int r) {
+        double av[2][TP][KM], ap[2][TP][RQ1];
+        auto gather = [&](double (&dst)[TP][KM], double (&dp)[TP][RQ1], int r) {
             const double *slice = img + r * NM * S;
 #pragma unroll
             for (int tq = 0; tq < TP; ++tq)
 #pragma unroll
-                for (int kp = 0; kp < TP; ++kp)
+                for (int kp = 0; kp < KM; ++kp)
                     dst[tq][kp] = slice[aoff[tq][kp]];
+#pragma unroll
+            for (int tq = 0; tq < TP; ++tq)
+#pragma unroll
+                for (int u = 0; u < RQ; ++u)
+                    dp[tq][u] = slice[poff[tq] + u];
         };
-        gather(av[0], 0);
+        gather(av[0], ap[0], 0);
 #pragma unroll
         for (int r = 0; r < NM; ++r)
         {
             if (r + 1 < NM)
-                gather(av[(r + 1) & 1], r + 1);
+                gather(av[(r + 1) & 1], ap[(r + 1) & 1], r + 1);
             double w1[TP];
 #pragma unroll
             for (int tq = 0; tq < TP; ++tq)
                 w1[tq] = 0.0;
 #pragma unroll
-            for (int kp = 0; kp < TP; ++kp)
+            for (int kp = 0; kp < KM; ++kp)
 #pragma unroll
                 for (int tq = 0; tq < TP; ++tq)
                     w1[tq] = mfma4(av[r & 1][tq][kp], opB0[kp], w1[tq]);
 #pragma unroll
+            for (int u = 0; u < RQ; ++u)
+#pragma unroll
+                for (int tq = 0; tq < TP; ++tq)
+                    w1[tq] = __builtin_fma(ap[r & 1][tq][u], pb0[u], w1[tq]);
+#pragma unroll
             for (int tj = 0; tj < TI; ++tj)
                 w2[r][tj] = 0.0;
 #pragma unroll
-            for (int tq = 0; tq < TP; ++tq)
+            for (int tq = 0; tq < KM; ++tq)
 #pragma unroll
                 for (int tj = 0; tj < TI; ++tj)
                     w2[r][tj] = mfma4(opB1[tj][tq], w1[tq], w2[r][tj]);
+#pragma unroll
+            for (int u = 0; u < RQ; ++u)
+            {
+                // W1[q = 4 KM + u][i] sits in w1[KM] on the lanes with hi = u: every lane takes it from lane 16 u + (lane & 15)
+                const double wq = lane_gather(w1[KM < TP ? KM : TP - 1], 16 * u + (lane & 15));
+#pragma unroll
+                for (int tj = 0; tj < TI; ++tj)
+                    w2[r][tj] = __builtin_fma(pb1[tj][u], wq, w2[r][tj]);
+            }
             // W2 rows that may leave now: lane holds W2[r'][j = 4 tj + hi][i = 4 blk + lo].  The gathers of slice r + 1
             // are already issued (LDS operations of a wave execute in order), and a row never overlaps a later slice
             // than w2_store_after() names.
@@ -207,37 +267,45 @@ __global__ __launch_bounds__(kWave *WPB, MINW) void hex_mfma4_kernel(
         // ---- sweep 3 --------------------------------------------------------------------------------------------
         double o[DIRECT ? 1 : CG][TI];
         double *oe = out + c * (uint64_t)G::NQT;
-        double bv[2][TP];
-        int rrow[TP];
+        double bv[2][KM], bp[2][RQ1];
+        int rrow[KM];
 #pragma unroll
-        for (int kr = 0; kr < TP; ++kr)
+        for (int kr = 0; kr < KM; ++kr)
         {
             const int r = 4 * kr + hi;
             rrow[kr]    = (r < NM ? r : NM - 1) * W2S;
         }
-        auto gather3 = [&](double (&dst)[TP], int cg) {
+        auto gather3 = [&](double (&dst)[KM], double (&dp)[RQ1], int cg) {
             int pos = 16 * cg + 4 * blk + lo;
             if ((cg + 1) * 16 > NQ2)
                 pos = pos < NQ2 ? pos : NQ2 - 1;
 #pragma unroll
-            for (int kr = 0; kr < TP; ++kr)
+            for (int kr = 0; kr < KM; ++kr)
                 dst[kr] = img[rrow[kr] + pos];
+#pragma unroll
+            for (int u = 0; u < RQ; ++u)
+                dp[u] = img[(4 * KM + u) * W2S + pos];
         };
-        gather3(bv[0], 0);
+        gather3(bv[0], bp[0], 0);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg)
         {
             if (cg + 1 < CG)
-                gather3(bv[(cg + 1) & 1], cg + 1);
+                gather3(bv[(cg + 1) & 1], bp[(cg + 1) & 1], cg + 1);
             double(&oc)[TI] = o[DIRECT ? 0 : cg];
 #pragma unroll
             for (int tk = 0; tk < TI; ++tk)
                 oc[tk] = 0.0;
 #pragma unroll
-            for (int kr = 0; kr < TP; ++kr)
+            for (int kr = 0; kr < KM; ++kr)
 #pragma unroll
                 for (int tk = 0; tk < TI; ++tk)
                     oc[tk] = mfma4(opB2[tk][kr], bv[cg & 1][kr], oc[tk]);
+#pragma unroll
+            for (int u = 0; u < RQ; ++u)
+#pragma unroll
+                for (int tk = 0; tk < TI; ++tk)
+                    oc[tk] = __builtin_fma(pb2[tk][u], bp[cg & 1][u], oc[tk]);
             if constexpr (DIRECT)
             {
 #pragma unroll

@@ -202,11 +202,11 @@ inline int launch_hex_mfma(const HexArgsT<T> &a, hipStream_t s, int grid_overrid
     return e == hipSuccess ? SF_OK : (int)e;
 }
 
-template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool DIRECT = false, bool NTS = true>
+template <int NQ, int WPB, int MINW, int KMAP, int XG = 0, bool DIRECT = false, bool NTS = true, bool PEEL = true>
 inline int launch_hex_mfma4(const HexArgs &a, hipStream_t s, int grid_override = 0)
 {
     static OccCache cache = {};
-    auto kern            = hex_mfma4_kernel<NQ, WPB, MINW, KMAP, XG, false, DIRECT, NTS>;
+    auto kern            = hex_mfma4_kernel<NQ, WPB, MINW, KMAP, XG, false, DIRECT, NTS, PEEL>;
     constexpr size_t lds = hex_mfma4_lds_bytes<NQ, WPB, DIRECT>();
     static_assert(lds <= 160 * 1024, "LDS slab exceeds 160 KiB");
     if (a.nelmt == 0)

@@ -154,18 +154,20 @@ template <int NQ, int MW, int XG> void hex_mfma2_case(const HexArgs &a)
     }
 }
 
-template <int NQ, int WPB, int MW, int K, int XG, bool DIRECT = false, bool NTS = true> void hex_mfma4_case(const HexArgs &a)
+template <int NQ, int WPB, int MW, int K, int XG, bool DIRECT = false, bool NTS = true, bool PEEL = true>
+void hex_mfma4_case(const HexArgs &a)
 {
     if constexpr (NQ >= 9 && NQ <= 16 && hex_mfma4_lds_bytes<NQ, WPB>() <= 160 * 1024)
     {
         char label[96];
-        std::snprintf(label, sizeof label, "hex nq%d MFMA 4x4x4 WPB%d MW%d K%d xg%d%s", NQ, WPB, MW, K, XG, DIRECT ? (NTS ? " direct" : " direct, cached stores") : "");
+        std::snprintf(label, sizeof label, "hex nq%d MFMA 4x4x4 WPB%d MW%d K%d xg%d%s%s", NQ, WPB, MW, K, XG,
+                      DIRECT ? (NTS ? " direct" : " direct, cached stores") : "", PEEL ? "" : " nopeel");
         const double nm = NQ - 1;
         if (!tune::fits(label, sizeof(double) * a.nelmt * tune::ipow(NQ - 1, 3), sizeof(double) * a.nelmt * tune::ipow(NQ, 3),
                         sizeof(double) * (NQ - 1) * NQ))
             return;
         run(label, a.nelmt * nm * nm * nm, a.nelmt * 8.0 * (nm * nm * nm + (double)NQ * NQ * NQ), a.out,
-            a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma4<NQ, WPB, MW, K, XG, DIRECT, NTS>(a, 0); });
+            a.nelmt * (size_t)NQ * NQ * NQ, [&]() { return launch_hex_mfma4<NQ, WPB, MW, K, XG, DIRECT, NTS, PEEL>(a, 0); });
     }
 }
 
@@ -276,6 +278,8 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 2; ++rep)
     {
         hex_mfma4_pair_case<TUNE_NQ, 2, 64>(a);
+        hex_mfma4_case<TUNE_NQ, 1, 2, 1, 64, false, true, false>(a); // without the peeled k remainder (nq 14, 15 differ)
+        hex_mfma4_case<TUNE_NQ, 1, 1, 1, 64, false, true, false>(a);
         hex_mfma4_case<TUNE_NQ, 1, 2, 1, 64, true, false>(a);
         hex_mfma4_case<TUNE_NQ, 1, 1, 1, 64, true, false>(a);
         hex_mfma4_case<TUNE_NQ, 1, 1, 1, 64, true>(a);

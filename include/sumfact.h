@@ -52,7 +52,7 @@ enum
 };
 
 /* Kernel strategies (benchmark columns / tuning).  SF_VARIANT_AUTO picks the fastest measured: 3D isotropic nq 2..11
- * WAVE, 12 and 16 MFMA4, 13..15 MFMA; 2D isotropic nq 2..20 WAVE, 21..31 MFMA4, 32 MFMA; 3D anisotropic extents: WAVE where the shape
+ * WAVE, 12 / 14 / 16 MFMA4, 13 / 15 MFMA; 2D isotropic nq 2..20 WAVE, 21..31 MFMA4, 32 MFMA; 3D anisotropic extents: WAVE where the shape
  * is one of the compile-time triples of csrc/bwdtrans_rt.hip, else WAVE_RT up to nq = 8 per direction (also taken for
  * isotropic shapes in buffers that are only 8-byte aligned); anything else (2D anisotropic, any higher order) GENERIC,
  * which runs every extent: LDS-resident while one element's images fit the
