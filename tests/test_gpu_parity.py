@@ -414,6 +414,36 @@ def test_line_alignment_offsets(sf, oracle, torch_mod, dim):
             assert bool((head == -7.0).all()) and bool((tail == -7.0).all()), (dim, nq, nelmt)
 
 
+@pytest.mark.parametrize("nq", range(12, 17))
+def test_hex_matrix_core_orders_line_offsets_and_guard_bands(sf, oracle, torch_mod, nq):
+    """3D nq 12..16 through AUTO (hex_mfma4_kernel at 12 / 14 / 16 -- nq 16 stores its accumulators directly --,
+    hex_mfma_kernel at 13 / 15) and through both output paths of the 4x4x4 kernel: every 16-byte-multiple offset of `in`
+    and `out` inside a 128-byte line gives the oracle's result, and nothing is written before or after the output view."""
+    import os
+    GUARD = 32
+    nmt, nqt = (nq - 1) ** 3, nq ** 3
+    bs = [sf.fill_random((nq - 1) * nq, 60 + d) for d in range(3)]
+    try:
+        for variant, cfg in (("auto", None), ("mfma4", "1"), ("mfma4", "3")):
+            if cfg is None:
+                os.environ.pop("SF_HEX_MFMA4_CFG", None)
+            else:
+                os.environ["SF_HEX_MFMA4_CFG"] = cfg
+            for nelmt, off_in, off_out in ((131, 2, 0), (300, 6, 4), (77, 10, 14), (64, 0, 8), (5, 12, 2)):
+                xbuf = sf.fill_random(nelmt * nmt + 16, 7 * nq + nelmt)
+                x = xbuf[off_in:off_in + nelmt * nmt]
+                obuf = torch_mod.full((nelmt * nqt + 2 * GUARD,), -7.0, dtype=torch_mod.float64, device="cuda")
+                out = obuf[GUARD + off_out - 16:GUARD + off_out - 16 + nelmt * nqt]
+                sf.bwdtrans_hex((nq,) * 3, *bs, x, out=out, variant=variant)
+                ref = oracle.bwdtrans_hex((nq,) * 3, nelmt, *[_np(b) for b in bs], _np(x).copy())
+                assert oracle.rel_err(_np(out), ref) <= TOL, (variant, cfg, nq, nelmt, off_in, off_out)
+                head = obuf[:GUARD + off_out - 16]
+                tail = obuf[GUARD + off_out - 16 + nelmt * nqt:]
+                assert bool((head == -7.0).all()) and bool((tail == -7.0).all()), (variant, cfg, nq, nelmt)
+    finally:
+        os.environ.pop("SF_HEX_MFMA4_CFG", None)
+
+
 @pytest.mark.parametrize("dim,nq", [(3, 8), (3, 10), (3, 5), (3, 13), (2, 16), (2, 20), (2, 28), (2, 9)])
 def test_xcd_window_tails(sf, oracle, dim, nq):
     """Workgroups are renumbered in windows of 8 * 64 (XCD runs); an element count that leaves many full windows
